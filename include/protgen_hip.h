@@ -1,0 +1,257 @@
+/* protgen_hip.h — C ABI of the MI355X (gfx950) engine for the ProtBERT GAN hot path.
+ *
+ * The reference (UfukTanriverdi8/ProtGen-GAN) has no FFI: its hot path is Python
+ * (models.py, loss.py, generate.py) over torch/transformers kernels.  Every entry point
+ * below therefore names the reference Python call sites whose arithmetic it replaces.
+ * All pointers are device pointers owned by the caller unless stated otherwise; nothing is
+ * retained after a call returns; `stream` is a hipStream_t passed as void*.  Functions
+ * return PG_OK (0) or a negative PG_ERR_* code; pg_strerror() names it.  No entry point
+ * allocates or frees device memory.
+ *
+ * Activation dtype `dtype` is PG_F32 (exact fp32 MFMA path, used for token-identical
+ * parity) or PG_BF16 (bf16 storage and MFMA inputs, fp32 accumulation and statistics).
+ * Parameters are always fp32 ("master"); bf16 compute additionally reads a bf16 copy of
+ * the same flat layout ("shadow").
+ */
+#ifndef PROTGEN_HIP_H
+#define PROTGEN_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_ERR_ARG (-1)
+#define PG_ERR_ALIGN (-2)
+#define PG_ERR_LAUNCH (-3)
+#define PG_ERR_UNSUPPORTED (-4)
+#define PG_ERR_WORKSPACE (-5)
+
+#define PG_F32 0
+#define PG_BF16 1
+
+#define PG_ACT_NONE 0
+#define PG_ACT_GELU 1      /* v = gelu(v); pre-activation optionally stored to aux */
+#define PG_ACT_MUL_DGELU 2 /* v *= gelu'(aux[m][n]) */
+
+const char* pg_strerror(int code);
+int pg_abi_version(void);
+
+/* ------------------------------------------------------------------ model description */
+typedef struct {
+  int vocab_size, hidden, layers, heads, inter, max_pos, type_vocab;
+  float ln_eps;
+} pg_model_cfg;
+
+/* Flat parameter layout (element offsets into the fp32 master / grad / bf16 shadow
+ * buffers).  `which` indexes the tensors of HF BertForMaskedLM
+ * (transformers/models/bert/modeling_bert.py) in this order: */
+enum {
+  PG_P_WORD_EMB = 0, PG_P_POS_EMB, PG_P_TYPE_EMB, PG_P_EMB_LN_G, PG_P_EMB_LN_B,
+  PG_P_MLM_BIAS, PG_P_MLM_W, PG_P_MLM_B, PG_P_MLM_LN_G, PG_P_MLM_LN_B,
+  PG_P_GLOBAL_COUNT
+};
+enum { /* per encoder layer; Q,K,V weights are adjacent so they form one [3H,H] matrix */
+  PG_L_WQ = 0, PG_L_WK, PG_L_WV, PG_L_BQ, PG_L_BK, PG_L_BV, PG_L_WO, PG_L_BO, PG_L_LN1_G, PG_L_LN1_B,
+  PG_L_W1, PG_L_B1, PG_L_W2, PG_L_B2, PG_L_LN2_G, PG_L_LN2_B,
+  PG_L_COUNT
+};
+int64_t pg_param_total(const pg_model_cfg* cfg);
+int64_t pg_param_offset_global(const pg_model_cfg* cfg, int which);
+int64_t pg_param_offset_layer(const pg_model_cfg* cfg, int layer, int which);
+int64_t pg_param_size_global(const pg_model_cfg* cfg, int which);
+int64_t pg_param_size_layer(const pg_model_cfg* cfg, int which);
+
+/* Critic classification head nn.Sequential(Linear,ReLU,Linear,ReLU,Linear,ReLU,Linear)
+ * (models.py:76-84): flat fp32 layout W0,b0,W2,b2,W4,b4,W6,b6 with dims H,H/2,H/4,H/16,1. */
+int64_t pg_head_total(int hidden);
+int64_t pg_head_offset(int hidden, int linear_index /*0..3*/, int is_bias);
+
+typedef struct {
+  const float* master; /* flat fp32 parameters */
+  float* grad;         /* flat fp32 gradients (same layout), or NULL */
+  const void* shadow;  /* flat bf16 copy of master, required when dtype == PG_BF16 */
+} pg_params;
+
+/* ------------------------------------------------------------------ K1/K7: GEMM
+ * C = epilogue(alpha * A.B) on the matrix cores; replaces every torch.matmul / F.linear of
+ * HF BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput
+ * (modeling_bert.py:111-136,175-177,282-293,325-351) and their autograd backward.
+ * a_kmajor: A stored [M][K] (1) or [K][M] (0); b_kmajor: B stored [N][K] (1) or [K][N] (0).
+ * Batch index z in [0,batch) splits as (z / batch_inner, z % batch_inner) with strides
+ * (s?o, s?i) in elements.  bias is fp32 [N]; residual/aux have the activation dtype.   */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int dtype, c_dtype, a_kmajor, b_kmajor;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int batch, batch_inner;
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi;
+  float alpha, beta;
+  const float* bias;
+  const void* residual; int64_t ldr;
+  void* aux; int64_t ldaux;
+  void* aux2; /* PG_ACT_MUL_DGELU only: optional store of v before the multiply (ld = ldaux) */
+  int act;
+} pg_gemm_desc;
+int pg_gemm(const pg_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ row-wise kernels (K3/K4/K9/K10)
+ * H must be 64, 128, 256, 512 or 1024 (one wavefront per row).                          */
+
+/* BertEmbeddings (modeling_bert.py:53-108): word[ids]+type[0]+pos[s] -> LayerNorm. ids int64 [B,S]. */
+int pg_embed_ln(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                const float* gamma, const float* beta, float eps, void* out, int B, int S, int H, void* stream);
+/* Same, also storing the pre-LayerNorm sum (needed by the embedding backward). */
+int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                 const float* gamma, const float* beta, float eps, void* out, void* sum_out, int B, int S, int H,
+                 void* stream);
+/* y = LayerNorm(x) (modeling_bert.py:289-293,347-351; residual is added by the GEMM epilogue). */
+int pg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                 int rows, int H, void* stream);
+/* dx = LN'(x)^T dy ; dgamma += sum dy*xhat ; dbeta += sum dy (dgamma/dbeta may be NULL).
+ * `partial` is fp32 scratch of 2*H*pg_ln_partial_rows(rows) floats.                   */
+int pg_ln_partial_rows(int rows);
+int pg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
+                     float* dgamma, float* dbeta, float* partial, int rows, int H, void* stream);
+/* Tangent (JVP): ydot = gamma * rstd * Proj(xdot). */
+int pg_layernorm_jvp(int dtype, const void* x, const void* xdot, const float* gamma, float eps, void* ydot,
+                     int rows, int H, void* stream);
+/* Second-order reverse of the (primal, tangent) pair used by the gradient penalty:
+ *   xbar = LN'(x)^T ybar + d/dx <gy, LN_jvp(x; xdot)>,
+ *   dgamma += sum ybar*xhat + sum gy*rstd*Proj(xdot), dbeta += sum ybar.
+ * ybar may be NULL (treated as zero).                                                    */
+int pg_layernorm_bwd2(int dtype, const void* x, const void* xdot, const void* gy, const void* ybar,
+                      const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* partial,
+                      int rows, int H, void* stream);
+/* ubar = gelu'(u)*gubar + gelu''(u)*udot*ggu  (GP second-order reverse of BertIntermediate's GELU). */
+int pg_gelu_bwd2(int dtype, const void* u, const void* udot, const void* ggu, const void* gubar, void* ubar,
+                 int64_t n, void* stream);
+/* db[n] += sum_rows dY[row][n]  (bias gradients). */
+int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float* db, void* stream);
+
+/* ------------------------------------------------------------------ attention over materialised scores (K2/K8/K10)
+ * scores/grad buffers are fp32 [Z][S][ldS] with ldS = pg_score_ld(S); mask is float [B][S]
+ * of 0/1 (NULL = all ones), Z = B*heads.  Softmax follows eager_attention_forward
+ * (modeling_bert.py:125-130) with the additive mask (1-m)*finfo(float32).min
+ * (modeling_utils.py:1012-1024).  Outputs of activation dtype have row stride ldS and
+ * zeros in columns >= S.                                                                */
+int pg_score_ld(int S);
+int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
+/* dS = P * (dP - rowsum(dP*P)) */
+int pg_softmax_bwd(int dtype, const float* dP, const void* P, void* dS, int Z, int S, void* stream);
+/* Sdot_out = Sdot ; Pdot = P * (Sdot - rowsum(P*Sdot)) */
+int pg_softmax_jvp(int dtype, const float* Sdot, const void* P, void* Sdot_out, void* Pdot, int Z, int S, void* stream);
+/* GP second-order reverse: given P, Sdot, gP = gctx.V^T, X = ctxbar.V^T + gctx.Vdot^T:
+ *   Pdot = P*(Sdot - r), r = rowsum(P*Sdot), c = rowsum(gP*P)
+ *   Pbar = X + gP*(Sdot - r) - c*Sdot ;  Sbar = P*(Pbar - rowsum(Pbar*P))              */
+int pg_softmax_bwd2(int dtype, const void* P, const void* Sdot, const float* gP, const float* X, void* Sbar,
+                    void* Pdot, int Z, int S, void* stream);
+
+/* ------------------------------------------------------------------ K5/K6: MLM head + sampler + unmask
+ * Replaces models.py:21-63 (softmax(logits/T), multinomial over every position,
+ * confidence gather, per-row top-k commit).                                              */
+/* logits[t][v] = hidden_t . word[v] + bias[v] (tied decoder, modeling_bert.py:484-496), fp32 out. */
+int pg_mlm_decode(int dtype, const void* t, const float* word, const float* bias, float* logits, int T, int H, int V,
+                  void* stream);
+/* Per token: p = softmax(logits/temperature); pred = argmax_v p_v / noise_v (== torch.multinomial
+ * under the same Exp(1) draw); conf = p[pred].  noise fp32 [T][V].                       */
+int pg_sample_tokens(const float* logits, const float* noise, float temperature, int T, int V, int64_t* pred,
+                     float* conf, void* stream);
+/* Per batch row (models.py:35-63): masks = ids==mask_id; k = all masks if fill_all else
+ * min(max(1, int(keep_percent * #{ids not in {pad,cls,sep}})), #masks); commit pred at the
+ * k masked positions of highest conf (ties: lowest index).  ids int64 [B][S] in place.
+ * counts int32 [B][2] = {committed, masks remaining after the commit} (may be NULL).     */
+int pg_commit_topk(int64_t* ids, const int64_t* pred, const float* conf, int B, int S, double keep_percent,
+                   int fill_all, int mask_id, int pad_id, int cls_id, int sep_id, int32_t* counts, void* stream);
+
+/* ------------------------------------------------------------------ critic head (models.py:76-84,104-105)
+ * All fp32.  x is the CLS row of the last hidden state: row b at hidden + b*row_stride
+ * (activation dtype).  `stash` holds the three post-ReLU activations and the input copy:
+ * pg_head_stash_floats(H) floats per batch row.                                          */
+int64_t pg_head_stash_floats(int hidden);
+int pg_head_forward(int dtype, const void* hidden, int64_t row_stride, const float* head, int B, int H, float* scores,
+                    float* stash, void* stream);
+/* Backward of sum_b w[b]*score_b: accumulates head grads (if ghead != NULL) and writes
+ * dx rows (activation dtype) to dhidden + b*row_stride (other rows untouched).          */
+int pg_head_backward(int dtype, const float* head, float* stash, const float* w, int B, int H, float* ghead,
+                     void* dhidden, int64_t row_stride, void* stream);
+/* GP second-order: tangent xdot (row b at hdot + b*row_stride) through the head with the
+ * primal's ReLU gates; accumulates ghead += scale * d<1, sdot>/dhead.  tstash is scratch of the
+ * same size as stash; sdot_out [B] optional. */
+int pg_head_jvp_grad(int dtype, const float* head, float* stash, const void* hdot, int64_t row_stride, int B,
+                     int H, float scale, float* ghead, float* tstash, float* sdot_out, void* stream);
+
+/* ------------------------------------------------------------------ K11: gradient-penalty reductions (loss.py:87-95)
+ * g [B][S*H] activation dtype, mask float [B][S].  norms[b] = ||g_b * mask||_2 ;
+ * gp = mean((norm-1)^2) ; v = scale * (2/B) * (norm-1)/norm * g * mask (the GP direction);
+ * scale is read from device memory (*scale_dev, NULL = 1) so the loss weight arriving from
+ * autograd needs no host synchronisation.                                                */
+int pg_gp_norms(int dtype, const void* g, const float* mask, int B, int S, int H, float* norms, float* gp_out,
+                void* stream);
+int pg_gp_direction(int dtype, const void* g, const float* mask, const float* norms, int B, int S, int H,
+                    const float* scale_dev, void* v, float* gp_out, void* stream);
+/* x = alpha_b * er + (1-alpha_b) * ef (loss.py:29); alpha fp32 [B]. */
+int pg_interpolate(int dtype, const void* er, const void* ef, const float* alpha, void* x, int B, int64_t per_sample,
+                   void* stream);
+/* der = alpha_b * dx ; def = (1-alpha_b) * dx */
+int pg_interpolate_bwd(int dtype, const void* dx, const float* alpha, void* der, void* def, int B,
+                       int64_t per_sample, void* stream);
+/* Embedding backward: LayerNorm backward of BertEmbeddings followed by scatter-add into the
+ * word / position / token-type tables (fp32 atomics).                                    */
+int pg_embed_scatter(int dtype, const void* dsum, const int64_t* ids, float* gword, float* gpos, float* gtype0, int B,
+                     int S, int H, void* stream);
+
+/* ------------------------------------------------------------------ K12: optimizer
+ * torch.optim.AdamW semantics (fully_masked_train.py:74-75,326): decoupled weight decay,
+ * bias correction with the 1-based `step`.  Optionally refreshes the bf16 shadow.        */
+int pg_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+             float beta2, float eps, float wd, int step, float grad_scale, void* stream);
+int pg_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int pg_cast_f32(const void* src_bf16, float* dst, int64_t n, void* stream);
+int pg_scale_f32(float* p, float s, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ engine: whole-pass orchestration
+ * One call runs a complete pass over all layers with the kernels above (no host sync).
+ * The caller provides the workspace and (for training) the stash buffers; sizes come from
+ * pg_workspace_bytes / pg_stash_bytes.  Requirements: head_dim == 64; for passes that
+ * stash, S % 64 == 0 is not required but score rows are padded to pg_score_ld(S).       */
+int64_t pg_workspace_bytes(const pg_model_cfg* cfg, int dtype, int B, int S);
+int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int S);
+
+/* Forward through embeddings (if ids != NULL, else x_in [B,S,H] is the encoder input, as in
+ * models.py:94-102 / loss.py:62-66) and all encoder layers.  mask: float [B,S] or NULL.
+ * hidden_out [B,S,H] activation dtype.  stash may be NULL (inference).  emb_sum_out
+ * (nullable, ids path only) receives the pre-LayerNorm embedding sum for the backward.   */
+int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
+                       const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes, void* stash,
+                       void* hidden_out, void* emb_sum_out, void* stream);
+/* MLM head up to logits (Generator.forward, models.py:14-16): fp32 logits [T][V]. */
+int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T, void* workspace,
+                  int64_t workspace_bytes, float* logits, void* stream);
+/* First-order backward of pg_encoder_forward from d_hidden [B,S,H] (activation dtype).
+ * flags: bit0 = accumulate parameter gradients into p->grad; bit1 = write every layer's
+ * adjoints into adj_stash (same layout as the forward stash; needed by the GP).
+ * dx_out (nullable) receives the gradient w.r.t. the encoder input (the embedding output;
+ * its own backward is pg_layernorm_bwd + pg_embed_scatter).                              */
+#define PG_BWD_PARAM_GRADS 1
+#define PG_BWD_SAVE_ADJOINTS 2
+int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                        void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* GP tangent-forward pass: xdot_in [B,S,H] -> hdot_out [B,S,H]; writes the tangent stash. */
+int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                   const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+/* GP second-order reverse over (primal stash, adjoint stash, tangent stash): accumulates
+ * d<v, ds/dx>/dtheta into p->grad (flags bit0; any loss weight is folded into v by
+ * pg_gp_direction) and writes the gradient w.r.t. the encoder input x to xbar_out (nullable). */
+int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                         const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,546 @@
+// Whole-pass orchestration of the ProtBERT encoder on one HIP stream: forward,
+// first-order backward, gradient-penalty tangent pass and second-order reverse pass.
+// Host code only; every launch goes through the kernels of gemm.hip / rowwise.hip /
+// misc.hip.  No allocation, no host synchronisation: the caller owns parameters,
+// workspace and stash buffers (sizes from pg_workspace_bytes / pg_stash_bytes).
+//
+// Stash layout (activation dtype), shared by the primal, adjoint and tangent stashes so
+// that the four passes address the same slot names:
+//   xs[l]  l = 0..L   input of layer l (xs[L] = output of the last layer)          [T][H]
+//   per layer: qkv [T][3H] | ss [Z][S][ldS] | ctx [T][H] | a [T][H] (pre-LN1) | h [T][H]
+//              u [T][I] (pre-GELU) | gu [T][I] | f [T][H] (pre-LN2)
+#include <string.h>
+#include "pg_common.h"
+#include "protgen_hip.h"
+
+namespace {
+
+struct Dims {
+  int B, S, H, I, nh, L, V, ldS;
+  long T, Z;
+  int es;  // activation element size
+};
+
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+struct StashLayout {
+  long xs, layer0, per_layer;
+  long o_qkv, o_ss, o_ctx, o_a, o_h, o_u, o_gu, o_f;
+  long total_bytes;
+};
+
+StashLayout stash_layout(const Dims& d) {
+  StashLayout s;
+  const long th = align_up(d.T * d.H * d.es, 256);
+  const long ti = align_up(d.T * d.I * d.es, 256);
+  const long t3 = align_up(d.T * 3 * d.H * d.es, 256);
+  const long ss = align_up(d.Z * d.S * d.ldS * d.es, 256);
+  s.xs = 0;
+  s.layer0 = th * (d.L + 1);
+  long o = 0;
+  s.o_qkv = o; o += t3;
+  s.o_ss = o; o += ss;
+  s.o_ctx = o; o += th;
+  s.o_a = o; o += th;
+  s.o_h = o; o += th;
+  s.o_u = o; o += ti;
+  s.o_gu = o; o += ti;
+  s.o_f = o; o += th;
+  s.per_layer = o;
+  s.total_bytes = s.layer0 + s.per_layer * d.L;
+  return s;
+}
+
+struct Slots {
+  char* x; char* y; char* qkv; char* ss; char* ctx; char* a; char* h; char* u; char* gu; char* f;
+};
+
+struct Workspace {
+  // fp32 score-sized buffers
+  float* sc0; float* sc1;
+  // activation-dtype temporaries
+  char* ss0; char* ss1;
+  char* qkv; char* ctx; char* a; char* h; char* u; char* gu; char* f; char* x0; char* x1;
+  float* ln_partial;
+  float* mlm_tmp;  // unused by the encoder passes
+  long total_bytes;
+};
+
+Workspace ws_layout(const Dims& d, char* base) {
+  Workspace w;
+  long o = 0;
+  auto take = [&](long bytes) { char* p = base ? base + o : nullptr; o += align_up(bytes, 256); return p; };
+  const long scb = d.Z * d.S * d.ldS * 4L;
+  w.sc0 = (float*)take(scb);
+  w.sc1 = (float*)take(scb);
+  w.ss0 = take(d.Z * d.S * d.ldS * (long)d.es);
+  w.ss1 = take(d.Z * d.S * d.ldS * (long)d.es);
+  w.qkv = take(d.T * 3 * d.H * d.es);
+  w.ctx = take(d.T * d.H * d.es);
+  w.a = take(d.T * d.H * d.es);
+  w.h = take(d.T * d.H * d.es);
+  w.u = take(d.T * d.I * d.es);
+  w.gu = take(d.T * d.I * d.es);
+  w.f = take(d.T * d.H * d.es);
+  w.x0 = take(d.T * d.H * d.es);
+  w.x1 = take(d.T * d.H * d.es);
+  w.ln_partial = (float*)take(2L * d.H * 1024 * 4);
+  w.mlm_tmp = nullptr;
+  w.total_bytes = o;
+  return w;
+}
+
+bool make_dims(const pg_model_cfg* c, int dtype, int B, int S, Dims& d) {
+  if (!c || B <= 0 || S <= 0) return false;
+  if (c->hidden % c->heads || c->hidden / c->heads != 64) return false;
+  if (dtype != PG_F32 && dtype != PG_BF16) return false;
+  d.B = B; d.S = S; d.H = c->hidden; d.I = c->inter; d.nh = c->heads; d.L = c->layers; d.V = c->vocab_size;
+  d.ldS = pg_score_ld(S);
+  d.T = (long)B * S; d.Z = (long)B * c->heads;
+  d.es = dtype == PG_F32 ? 4 : 2;
+  return true;
+}
+
+struct ParamView {
+  const pg_model_cfg* c; const pg_params* p; int dtype;
+  const float* m(long off) const { return p->master + off; }
+  float* g(long off) const { return p->grad ? p->grad + off : nullptr; }
+  // matrix operand in the compute dtype
+  const void* w(long off) const {
+    return dtype == PG_F32 ? (const void*)(p->master + off) : (const void*)((const bf16_t*)p->shadow + off);
+  }
+  long lo(int l, int which) const { return pg_param_offset_layer(c, l, which); }
+};
+
+#define CK(expr) do { int _rc = (expr); if (_rc != PG_OK) return _rc; } while (0)
+
+// Plain 2-D GEMM helper.
+struct G {
+  int dtype; hipStream_t st;
+  int run(const void* A, bool ak, long lda, const void* B, bool bk, long ldb, void* C, int cdt, long ldc, int M, int N,
+          int K, float alpha, float beta, const float* bias = nullptr, const void* res = nullptr, long ldr = 0,
+          int act = PG_ACT_NONE, void* aux = nullptr, long ldaux = 0, void* aux2 = nullptr) const {
+    pg_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.B = B; d.C = C; d.dtype = dtype; d.c_dtype = cdt; d.a_kmajor = ak; d.b_kmajor = bk;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.batch = 1; d.batch_inner = 1;
+    d.alpha = alpha; d.beta = beta; d.bias = bias; d.residual = res; d.ldr = ldr; d.aux = aux; d.ldaux = ldaux;
+    d.aux2 = aux2; d.act = act;
+    return pg_gemm(&d, st);
+  }
+  // Batched over (b, head).  Operands living in a [T][ld] activation buffer are addressed with
+  // (outer = S*ld, inner = 64); score-shaped operands with (outer = nh*S*ldS, inner = S*ldS).
+  int bat(const Dims& dm, const void* A, bool ak, long lda, bool a_score, const void* B, bool bk, long ldb, bool b_score,
+          void* C, int cdt, long ldc, bool c_score, int M, int N, int K, float alpha, float beta) const {
+    pg_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.B = B; d.C = C; d.dtype = dtype; d.c_dtype = cdt; d.a_kmajor = ak; d.b_kmajor = bk;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.batch = (int)dm.Z; d.batch_inner = dm.nh;
+    const long so = (long)dm.nh * dm.S * dm.ldS, si = (long)dm.S * dm.ldS;
+    d.sAo = a_score ? so : (long)dm.S * lda; d.sAi = a_score ? si : 64;
+    d.sBo = b_score ? so : (long)dm.S * ldb; d.sBi = b_score ? si : 64;
+    d.sCo = c_score ? so : (long)dm.S * ldc; d.sCi = c_score ? si : 64;
+    d.alpha = alpha; d.beta = beta;
+    return pg_gemm(&d, st);
+  }
+};
+
+inline char* off(char* p, long elems, int es) { return p + elems * es; }
+inline const char* off(const char* p, long elems, int es) { return p + elems * es; }
+
+Slots layer_slots(char* base, const StashLayout& sl, const Dims& d, int l) {
+  Slots s;
+  const long th = align_up(d.T * d.H * d.es, 256);
+  char* lb = base + sl.layer0 + sl.per_layer * l;
+  s.x = base + sl.xs + th * l;
+  s.y = base + sl.xs + th * (l + 1);
+  s.qkv = lb + sl.o_qkv; s.ss = lb + sl.o_ss; s.ctx = lb + sl.o_ctx; s.a = lb + sl.o_a; s.h = lb + sl.o_h;
+  s.u = lb + sl.o_u; s.gu = lb + sl.o_gu; s.f = lb + sl.o_f;
+  return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ parameter layout
+namespace {
+long gsize(const pg_model_cfg* c, int which) {
+  const long H = c->hidden;
+  switch (which) {
+    case PG_P_WORD_EMB: return (long)c->vocab_size * H;
+    case PG_P_POS_EMB: return (long)c->max_pos * H;
+    case PG_P_TYPE_EMB: return (long)c->type_vocab * H;
+    case PG_P_EMB_LN_G: case PG_P_EMB_LN_B: return H;
+    case PG_P_MLM_BIAS: return c->vocab_size;
+    case PG_P_MLM_W: return H * H;
+    case PG_P_MLM_B: case PG_P_MLM_LN_G: case PG_P_MLM_LN_B: return H;
+  }
+  return -1;
+}
+long lsize(const pg_model_cfg* c, int which) {
+  const long H = c->hidden, I = c->inter;
+  switch (which) {
+    case PG_L_WQ: case PG_L_WK: case PG_L_WV: case PG_L_WO: return H * H;
+    case PG_L_BQ: case PG_L_BK: case PG_L_BV: case PG_L_BO: return H;
+    case PG_L_LN1_G: case PG_L_LN1_B: case PG_L_LN2_G: case PG_L_LN2_B: return H;
+    case PG_L_W1: return I * H;
+    case PG_L_B1: return I;
+    case PG_L_W2: return H * I;
+    case PG_L_B2: return H;
+  }
+  return -1;
+}
+// every tensor starts on an 8-element boundary so bf16 operands stay 16-byte aligned
+long pad8(long n) { return (n + 7) / 8 * 8; }
+long globals_total(const pg_model_cfg* c) {
+  long o = 0;
+  for (int i = 0; i < PG_P_GLOBAL_COUNT; ++i) o += pad8(gsize(c, i));
+  return o;
+}
+long layer_total(const pg_model_cfg* c) {
+  long o = 0;
+  for (int i = 0; i < PG_L_COUNT; ++i) o += pad8(lsize(c, i));
+  return o;
+}
+}  // namespace
+
+extern "C" int64_t pg_param_size_global(const pg_model_cfg* c, int which) { return c ? gsize(c, which) : -1; }
+extern "C" int64_t pg_param_size_layer(const pg_model_cfg* c, int which) { return c ? lsize(c, which) : -1; }
+extern "C" int64_t pg_param_offset_global(const pg_model_cfg* c, int which) {
+  if (!c || which < 0 || which >= PG_P_GLOBAL_COUNT) return -1;
+  long o = 0;
+  for (int i = 0; i < which; ++i) o += pad8(gsize(c, i));
+  return o;
+}
+extern "C" int64_t pg_param_offset_layer(const pg_model_cfg* c, int layer, int which) {
+  if (!c || which < 0 || which >= PG_L_COUNT || layer < 0 || layer >= c->layers) return -1;
+  long o = globals_total(c) + layer_total(c) * layer;
+  for (int i = 0; i < which; ++i) o += pad8(lsize(c, i));
+  return o;
+}
+extern "C" int64_t pg_param_total(const pg_model_cfg* c) { return c ? globals_total(c) + layer_total(c) * c->layers : -1; }
+
+extern "C" int64_t pg_workspace_bytes(const pg_model_cfg* cfg, int dtype, int B, int S) {
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d)) return -1;
+  return ws_layout(d, nullptr).total_bytes;
+}
+extern "C" int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int S) {
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d)) return -1;
+  return stash_layout(d).total_bytes;
+}
+
+// ------------------------------------------------------------------ forward
+extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
+                                  const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes,
+                                  void* stash, void* hidden_out, void* emb_sum_out, void* stream) {
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d) || !p || !p->master || (!ids && !x_in) || !workspace) return PG_ERR_ARG;
+  if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
+  if (!stash && !hidden_out) return PG_ERR_ARG;
+  if (d.ldS > 1024) return PG_ERR_UNSUPPORTED;
+  Workspace w = ws_layout(d, (char*)workspace);
+  if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
+  StashLayout sl = stash_layout(d);
+
+  char* x = stash ? (char*)stash + sl.xs : w.x0;
+  if (ids) {
+    CK(pg_embed_ln2(dtype, ids, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)),
+                    pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)),
+                    pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)), cfg->ln_eps, x, emb_sum_out, B, S, H, st));
+  } else {
+    if (hipMemcpyAsync(x, x_in, (size_t)d.T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  for (int l = 0; l < d.L; ++l) {
+    Slots s;
+    if (stash) {
+      s = layer_slots((char*)stash, sl, d, l);
+    } else {
+      s.x = x; s.y = (x == w.x0) ? w.x1 : w.x0;
+      s.qkv = w.qkv; s.ss = w.ss0; s.ctx = w.ctx; s.a = w.a; s.h = w.h; s.u = nullptr; s.gu = w.gu; s.f = w.f;
+    }
+    if (l == d.L - 1 && !stash) s.y = (char*)hidden_out;
+    // QKV projection (BertSelfAttention.query/key/value as one [3H,H] matrix)
+    CK(g.run(s.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, s.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f,
+             pv.m(pv.lo(l, PG_L_BQ))));
+    // scores = Q K^T / 8
+    CK(g.bat(d, s.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+             0.125f, 0.f));
+    CK(pg_softmax_fwd(dtype, w.sc0, mask, s.ss, B, d.nh, S, st));
+    // ctx = P V
+    CK(g.bat(d, s.ss, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, s.ctx, dtype, H, false, S, 64, S, 1.f,
+             0.f));
+    // a = ctx Wo^T + bo + x ; h = LN1(a)
+    CK(g.run(s.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, s.a, dtype, H, T, H, H, 1.f, 0.f, pv.m(pv.lo(l, PG_L_BO)),
+             s.x, H));
+    CK(pg_layernorm(dtype, s.a, pv.m(pv.lo(l, PG_L_LN1_G)), pv.m(pv.lo(l, PG_L_LN1_B)), cfg->ln_eps, s.h, T, H, st));
+    // gu = gelu(h W1^T + b1) ; f = gu W2^T + b2 + h ; y = LN2(f)
+    CK(g.run(s.h, true, H, pv.w(pv.lo(l, PG_L_W1)), true, H, s.gu, dtype, I, T, I, H, 1.f, 0.f, pv.m(pv.lo(l, PG_L_B1)),
+             nullptr, 0, PG_ACT_GELU, s.u, I));
+    CK(g.run(s.gu, true, I, pv.w(pv.lo(l, PG_L_W2)), true, I, s.f, dtype, H, T, H, I, 1.f, 0.f, pv.m(pv.lo(l, PG_L_B2)),
+             s.h, H));
+    CK(pg_layernorm(dtype, s.f, pv.m(pv.lo(l, PG_L_LN2_G)), pv.m(pv.lo(l, PG_L_LN2_B)), cfg->ln_eps, s.y, T, H, st));
+    x = s.y;
+  }
+  if (stash && hidden_out) {
+    if (hipMemcpyAsync(hidden_out, x, (size_t)d.T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  return PG_OK;
+}
+
+// MLM head: t = LN(gelu(hidden W^T + b)) ; logits = t word^T + bias
+extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T,
+                             void* workspace, int64_t workspace_bytes, float* logits, void* stream) {
+  if (!cfg || !p || !hidden || !workspace || !logits || T <= 0) return PG_ERR_ARG;
+  const int H = cfg->hidden, es = dtype == PG_F32 ? 4 : 2;
+  const long need = 2 * align_up((long)T * H * es, 256);
+  if (need > workspace_bytes) return PG_ERR_WORKSPACE;
+  char* t0 = (char*)workspace;
+  char* t1 = t0 + align_up((long)T * H * es, 256);
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  CK(g.run(hidden, true, H, pv.w(pg_param_offset_global(cfg, PG_P_MLM_W)), true, H, t0, dtype, H, T, H, H, 1.f, 0.f,
+           pv.m(pg_param_offset_global(cfg, PG_P_MLM_B)), nullptr, 0, PG_ACT_GELU, nullptr, 0));
+  CK(pg_layernorm(dtype, t0, pv.m(pg_param_offset_global(cfg, PG_P_MLM_LN_G)), pv.m(pg_param_offset_global(cfg, PG_P_MLM_LN_B)),
+                  cfg->ln_eps, t1, T, H, st));
+  return pg_mlm_decode(dtype, t1, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)),
+                       pv.m(pg_param_offset_global(cfg, PG_P_MLM_BIAS)), logits, T, H, cfg->vocab_size, st);
+}
+
+// ------------------------------------------------------------------ first-order backward
+extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                                   void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  (void)mask;
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
+  const bool grads = flags & PG_BWD_PARAM_GRADS, save = flags & PG_BWD_SAVE_ADJOINTS;
+  if (grads && !p->grad) return PG_ERR_ARG;
+  if (save && !adj_stash) return PG_ERR_ARG;
+  if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
+  const int epc = dtype == PG_F32 ? 4 : 8;
+  if (S % epc) return PG_ERR_UNSUPPORTED;  // m-major operands of extent S
+  Workspace w = ws_layout(d, (char*)workspace);
+  if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
+  StashLayout sl = stash_layout(d);
+  const size_t th_bytes = (size_t)d.T * H * es;
+
+  char* dy = (char*)d_hidden;
+  if (save) {
+    Slots last = layer_slots((char*)adj_stash, sl, d, d.L - 1);
+    if (hipMemcpyAsync(last.y, dy, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  for (int l = d.L - 1; l >= 0; --l) {
+    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    Slots a;  // adjoint buffers of this layer
+    if (save) {
+      a = layer_slots((char*)adj_stash, sl, d, l);
+    } else {
+      a.qkv = w.qkv; a.ss = w.ss0; a.ctx = w.ctx; a.a = w.a; a.h = w.h; a.u = w.u; a.gu = w.gu; a.f = w.f;
+      a.x = (dy == w.x0) ? w.x1 : w.x0;
+    }
+    if (l == 0 && dx_out && !save) a.x = (char*)dx_out;
+    // LN2
+    CK(pg_layernorm_bwd(dtype, s.f, dy, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, a.f,
+                        grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
+                        w.ln_partial, T, H, st));
+    if (grads) {
+      CK(g.run(a.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, a.f, H, T, H, pv.g(pv.lo(l, PG_L_B2)), st));
+    }
+    // d gu = df W2 ; du = dgu * gelu'(u)
+    if (save) {
+      CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.gu, dtype, I, T, I, H, 1.f, 0.f));
+      CK(pg_gelu_bwd2(dtype, s.u, nullptr, nullptr, a.gu, a.u, (int64_t)d.T * I, st));
+    } else {
+      CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.u, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
+               PG_ACT_MUL_DGELU, s.u, I));
+    }
+    if (grads) {
+      CK(g.run(a.u, false, I, s.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, a.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
+    }
+    // dh = du W1 + df
+    CK(g.run(a.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, a.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, a.f, H));
+    // LN1
+    CK(pg_layernorm_bwd(dtype, s.a, a.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, a.a,
+                        grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
+                        w.ln_partial, T, H, st));
+    if (grads) {
+      CK(g.run(a.a, false, H, s.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, a.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
+    }
+    // dctx = da Wo
+    CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
+    // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
+    CK(g.bat(d, a.ctx, true, H, false, off(s.qkv, 2 * H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f,
+             0.f));
+    CK(pg_softmax_bwd(dtype, w.sc0, s.ss, a.ss, (int)d.Z, S, st));
+    CK(g.bat(d, a.ss, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, a.qkv, dtype, 3 * H, false, S, 64, S,
+             0.125f, 0.f));
+    CK(g.bat(d, a.ss, false, d.ldS, true, s.qkv, false, 3 * H, false, off(a.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+             0.125f, 0.f));
+    CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+             0.f));
+    if (grads) {
+      CK(g.run(a.qkv, false, 3 * H, s.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+    }
+    // dx = dqkv Wqkv + da
+    CK(g.run(a.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, a.x, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, a.a, H));
+    dy = a.x;
+  }
+  if (dx_out && dy != (char*)dx_out) {
+    if (hipMemcpyAsync(dx_out, dy, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  return PG_OK;
+}
+
+// ------------------------------------------------------------------ GP tangent-forward pass
+extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                              const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !xdot_in || !tan_stash || !workspace) return PG_ERR_ARG;
+  if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
+  Workspace w = ws_layout(d, (char*)workspace);
+  if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
+  StashLayout sl = stash_layout(d);
+  const size_t th_bytes = (size_t)d.T * H * es;
+  if (hipMemcpyAsync((char*)tan_stash + sl.xs, xdot_in, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return PG_ERR_LAUNCH;
+  for (int l = 0; l < d.L; ++l) {
+    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    const Slots t = layer_slots((char*)tan_stash, sl, d, l);
+    CK(g.run(t.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, t.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f));
+    // Sdot = (Qdot K^T + Q Kdot^T)/8
+    CK(g.bat(d, t.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+             0.125f, 0.f));
+    CK(g.bat(d, s.qkv, true, 3 * H, false, off(t.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+             0.125f, 1.f));
+    CK(pg_softmax_jvp(dtype, w.sc0, s.ss, t.ss, w.ss0, (int)d.Z, S, st));
+    // ctxdot = Pdot V + P Vdot
+    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
+             0.f));
+    CK(g.bat(d, s.ss, true, d.ldS, true, off(t.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
+             1.f));
+    CK(g.run(t.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, t.a, dtype, H, T, H, H, 1.f, 0.f, nullptr, t.x, H));
+    CK(pg_layernorm_jvp(dtype, s.a, t.a, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, t.h, T, H, st));
+    CK(g.run(t.h, true, H, pv.w(pv.lo(l, PG_L_W1)), true, H, t.gu, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
+             PG_ACT_MUL_DGELU, s.u, I, t.u));
+    CK(g.run(t.gu, true, I, pv.w(pv.lo(l, PG_L_W2)), true, I, t.f, dtype, H, T, H, I, 1.f, 0.f, nullptr, t.h, H));
+    CK(pg_layernorm_jvp(dtype, s.f, t.f, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, t.y, T, H, st));
+  }
+  if (hdot_out) {
+    const Slots t = layer_slots((char*)tan_stash, sl, d, d.L - 1);
+    if (hipMemcpyAsync(hdot_out, t.y, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  return PG_OK;
+}
+
+// ------------------------------------------------------------------ GP second-order reverse pass
+extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
+                                    const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  Dims d;
+  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
+  const bool grads = flags & PG_BWD_PARAM_GRADS;
+  if (grads && !p->grad) return PG_ERR_ARG;
+  if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
+  const int epc = dtype == PG_F32 ? 4 : 8;
+  if (S % epc) return PG_ERR_UNSUPPORTED;
+  Workspace w = ws_layout(d, (char*)workspace);
+  if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
+  StashLayout sl = stash_layout(d);
+  const size_t th_bytes = (size_t)d.T * H * es;
+
+  char* ybar = nullptr;  // second-order adjoint of the layer output (zero above the last layer)
+  for (int l = d.L - 1; l >= 0; --l) {
+    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    const Slots a = layer_slots((char*)const_cast<void*>(adj_stash), sl, d, l);
+    const Slots t = layer_slots((char*)const_cast<void*>(tan_stash), sl, d, l);
+    char* xbar = (ybar == w.x0) ? w.x1 : w.x0;
+    // LN2: fbar
+    CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, w.f,
+                         grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
+                         w.ln_partial, T, H, st));
+    if (grads) {
+      CK(g.run(w.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
+      CK(g.run(a.f, false, H, t.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, w.f, H, T, H, pv.g(pv.lo(l, PG_L_B2)), st));
+    }
+    // gubar = fbar W2 ; ubar = gelu'(u) gubar + gelu''(u) udot ggu
+    CK(g.run(w.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
+    CK(pg_gelu_bwd2(dtype, s.u, t.u, a.gu, w.gu, w.u, (int64_t)d.T * I, st));
+    if (grads) {
+      CK(g.run(w.u, false, I, s.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
+      CK(g.run(a.u, false, I, t.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, w.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
+    }
+    // hbar = ubar W1 + fbar
+    CK(g.run(w.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, w.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, w.f, H));
+    // LN1: abar
+    CK(pg_layernorm_bwd2(dtype, s.a, t.a, a.h, w.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, w.a,
+                         grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
+                         w.ln_partial, T, H, st));
+    if (grads) {
+      CK(g.run(w.a, false, H, s.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
+      CK(g.run(a.a, false, H, t.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, w.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
+    }
+    // ctxbar = abar Wo
+    CK(g.run(w.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
+    // attention second order
+    const char* v = off(s.qkv, 2 * H, es);
+    const char* vdot = off(t.qkv, 2 * H, es);
+    CK(g.bat(d, a.ctx, true, H, false, v, true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // gP
+    CK(g.bat(d, w.ctx, true, H, false, v, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // X
+    CK(g.bat(d, a.ctx, true, H, false, vdot, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 1.f));
+    CK(pg_softmax_bwd2(dtype, s.ss, t.ss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)d.Z, S, st));
+    // qbar = (Sbar K + gS Kdot)/8
+    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, w.qkv, dtype, 3 * H, false, S, 64, S,
+             0.125f, 0.f));
+    CK(g.bat(d, a.ss, true, d.ldS, true, off(t.qkv, H, es), false, 3 * H, false, w.qkv, dtype, 3 * H, false, S, 64, S,
+             0.125f, 1.f));
+    // kbar = (Sbar^T Q + gS^T Qdot)/8
+    CK(g.bat(d, w.ss0, false, d.ldS, true, s.qkv, false, 3 * H, false, off(w.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+             0.125f, 0.f));
+    CK(g.bat(d, a.ss, false, d.ldS, true, t.qkv, false, 3 * H, false, off(w.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+             0.125f, 1.f));
+    // vbar = P^T ctxbar + Pdot^T gctx
+    CK(g.bat(d, s.ss, false, d.ldS, true, w.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+             0.f));
+    CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+             1.f));
+    if (grads) {
+      CK(g.run(w.qkv, false, 3 * H, s.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
+      CK(g.run(a.qkv, false, 3 * H, t.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
+      CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+    }
+    // xbar = qkvbar Wqkv + abar
+    CK(g.run(w.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, xbar, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, w.a, H));
+    ybar = xbar;
+  }
+  if (xbar_out) {
+    if (hipMemcpyAsync(xbar_out, ybar, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+  }
+  return PG_OK;
+}

@@ -1,0 +1,353 @@
+// Batched strided GEMM on the CDNA4 matrix cores.
+//
+//   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(k,n) )
+//
+// One kernel template covers every contraction of the ProtBERT path: the Linear layers
+// (X W^T), their input gradients (dY W), their weight gradients (dY^T X), and the
+// attention products over materialised score matrices.  Each operand is either
+// "k-major" (the reduction index is the contiguous one: A[m][k], B[n][k]) or
+// "m-major" (the free index is contiguous: A stored [k][m], B stored [k][n]).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
+// 4x4 MFMA tiles of 16x16).  bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).  Tiles are staged through LDS with a
+// two-buffer pipeline (global loads for tile t+1 are issued before the MFMAs of tile t
+// and written to the other buffer afterwards).  k-major fragments are read with
+// ds_read_b128; m-major bf16 fragments with the transposing ds_read_b64_tr_b16.
+// The MFMA is issued with the operands swapped (D = Bt * At) so that a lane owns four
+// consecutive n of one output row, which makes every epilogue access an 8/16-byte vector.
+#include "pg_common.h"
+#include "protgen_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+
+template <typename T> struct GemmCfg;
+template <> struct GemmCfg<bf16_t> {
+  static constexpr int BK = 64, EPC = 8, KSTEP = 32;
+  static constexpr int LDK = BK + 8;     // k-major row stride (elements): 144 B
+  static constexpr int LDM = 128 + 16;   // m-major row stride (elements): 288 B
+};
+template <> struct GemmCfg<float> {
+  static constexpr int BK = 16, EPC = 4, KSTEP = 4;
+  static constexpr int LDK = BK + 4;     // 80 B
+  static constexpr int LDM = 128 + 4;    // 528 B
+};
+
+template <typename T> constexpr int op_elems() {
+  return (BM * GemmCfg<T>::LDK > GemmCfg<T>::BK * GemmCfg<T>::LDM) ? BM * GemmCfg<T>::LDK
+                                                                   : GemmCfg<T>::BK * GemmCfg<T>::LDM;
+}
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int batch_inner;
+  long sAo, sAi, sBo, sBi, sCo, sCi;
+  float alpha, beta;
+  const float* bias;
+  const void* residual; long ldr;
+  void* aux; long ldaux;
+  void* aux2;
+  int act;
+  int vec_ok;
+};
+
+// ---- global -> register staging of one operand tile -------------------------------------
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage_load(const T* __restrict__ base, long ld, int row0, int rows_max,
+                                           int k0, int K, uint4 (&regs)[GemmCfg<T>::BK * 128 / GemmCfg<T>::EPC / NTHREADS]) {
+  using C = GemmCfg<T>;
+  constexpr int NCH = C::BK * 128 / C::EPC / NTHREADS;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = t + i * NTHREADS;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (KMAJOR) {
+      constexpr int CPR = C::BK / C::EPC;
+      const int r = c / CPR, kc = c % CPR;
+      const int k = k0 + kc * C::EPC;
+      int rg = row0 + r;
+      rg = rg < rows_max ? rg : rows_max - 1;
+      if (k < K) {
+        v = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k);
+        if (k + C::EPC > K) {  // chunk straddles the end of the reduction: zero the tail
+          T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+          for (int j = 0; j < C::EPC; ++j)
+            if (k + j >= K) e[j] = (T)0;
+        }
+      }
+    } else {
+      constexpr int CPR = 128 / C::EPC;
+      const int kr = c / CPR, mc = c % CPR;
+      const int k = k0 + kr;
+      int m = row0 + mc * C::EPC;
+      m = m <= rows_max - C::EPC ? m : rows_max - C::EPC;
+      if (k < K) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + m);
+    }
+    regs[i] = v;
+  }
+}
+
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage_store(T* lds, const uint4 (&regs)[GemmCfg<T>::BK * 128 / GemmCfg<T>::EPC / NTHREADS]) {
+  using C = GemmCfg<T>;
+  constexpr int NCH = C::BK * 128 / C::EPC / NTHREADS;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = t + i * NTHREADS;
+    if (KMAJOR) {
+      constexpr int CPR = C::BK / C::EPC;
+      const int r = c / CPR, kc = c % CPR;
+      *reinterpret_cast<uint4*>(lds + r * C::LDK + kc * C::EPC) = regs[i];
+    } else {
+      constexpr int CPR = 128 / C::EPC;
+      const int kr = c / CPR, mc = c % CPR;
+      *reinterpret_cast<uint4*>(lds + kr * C::LDM + mc * C::EPC) = regs[i];
+    }
+  }
+}
+
+// ---- LDS -> MFMA fragments --------------------------------------------------------------
+// bf16 fragment of the 16x16x32 MFMA: lane (r = lane&15, g = lane>>4) holds 8 values
+// X[row0 + r][kk*32 + 8g + j], j = 0..7.
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8_t frag_bf16(const bf16_t* lds, int row0, int kk, int lane) {
+  using C = GemmCfg<bf16_t>;
+  const int r = lane & 15, g = lane >> 4;
+  if (KMAJOR) {
+    uint4 v = *reinterpret_cast<const uint4*>(lds + (row0 + r) * C::LDK + kk * 32 + 8 * g);
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    // Transposing read: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3
+    // of a 4x16 block and receives column (lane&15) of its 4 rows.
+    const int q = r >> 2, p = r & 3;
+    const bf16_t* a0 = lds + (kk * 32 + 8 * g + q) * C::LDM + row0 + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * C::LDM));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+// fp32 fragment of the 16x16x4 MFMA: lane holds X[row0 + r][kk*4 + g].
+template <bool KMAJOR>
+__device__ __forceinline__ float frag_f32(const float* lds, int row0, int kk, int lane) {
+  using C = GemmCfg<float>;
+  const int r = lane & 15, g = lane >> 4;
+  if (KMAJOR) return lds[(row0 + r) * C::LDK + kk * 4 + g];
+  return lds[(kk * 4 + g) * C::LDM + row0 + r];
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void mma_tile_bf16(const bf16_t* la, const bf16_t* lb, f32x4 (&acc)[4][4], int wr,
+                                              int wc, int lane) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bf16x8_t af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag_bf16<AK>(la, wr * 64 + i * 16, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = frag_bf16<BK_>(lb, wc * 64 + j * 16, kk, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+  }
+}
+template <bool AK, bool BK_>
+__device__ __forceinline__ void mma_tile_f32(const float* la, const float* lb, f32x4 (&acc)[4][4], int wr, int wc,
+                                             int lane) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    float af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag_f32<AK>(la, wr * 64 + i * 16, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = frag_f32<BK_>(lb, wc * 64 + j * 16, kk, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <typename TC> __device__ __forceinline__ void load4(const TC* p, float* o, bool vec, int nvalid) {
+  if (vec) {
+    VecIO<TC, 4>::load(p, o);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = j < nvalid ? to_f32<TC>(p[j]) : 0.f;
+  }
+}
+template <typename TC> __device__ __forceinline__ void store4(TC* p, const float* o, bool vec, int nvalid) {
+  if (vec) {
+    VecIO<TC, 4>::store(p, o);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) p[j] = from_f32<TC>(o[j]);
+  }
+}
+
+template <typename T, typename TC, bool AK, bool BK_>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
+  using C = GemmCfg<T>;
+  constexpr int OPE = op_elems<T>();
+  constexpr int NCH = C::BK * 128 / C::EPC / NTHREADS;
+  __shared__ __align__(16) T smem[4 * OPE];
+
+  const int z = blockIdx.z;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const T* A = reinterpret_cast<const T*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const T* B = reinterpret_cast<const T*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[NCH], rb[NCH];
+  const int nt = (g.K + C::BK - 1) / C::BK;
+  stage_load<T, AK>(A, g.lda, bm, g.M, 0, g.K, ra);
+  stage_load<T, BK_>(B, g.ldb, bn, g.N, 0, g.K, rb);
+  stage_store<T, AK>(smem, ra);
+  stage_store<T, BK_>(smem + OPE, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    T* la = smem + cur * 2 * OPE;
+    T* lb = la + OPE;
+    if (t + 1 < nt) {
+      stage_load<T, AK>(A, g.lda, bm, g.M, (t + 1) * C::BK, g.K, ra);
+      stage_load<T, BK_>(B, g.ldb, bn, g.N, (t + 1) * C::BK, g.K, rb);
+    }
+    if constexpr (sizeof(T) == 2)
+      mma_tile_bf16<AK, BK_>(reinterpret_cast<const bf16_t*>(la), reinterpret_cast<const bf16_t*>(lb), acc, wr, wc, lane);
+    else
+      mma_tile_f32<AK, BK_>(reinterpret_cast<const float*>(la), reinterpret_cast<const float*>(lb), acc, wr, wc, lane);
+    if (t + 1 < nt) {
+      T* na = smem + (cur ^ 1) * 2 * OPE;
+      stage_store<T, AK>(na, ra);
+      stage_store<T, BK_>(na + OPE, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns C[m][n..n+3], m = ... + (lane&15), n = ... + 4*(lane>>4)
+  const bool vec = g.vec_ok != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm + wr * 64 + i * 16 + (lane & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = bn + wc * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= g.N) continue;
+      const int nvalid = g.N - n < 4 ? g.N - n : 4;
+      const bool v4 = vec && nvalid == 4;
+      float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+      if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) v[e] += g.bias[n + e];
+      }
+      if (g.act == PG_ACT_GELU) {
+        if (g.aux) store4<T>(reinterpret_cast<T*>(g.aux) + (long)m * g.ldaux + n, v, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      } else if (g.act == PG_ACT_MUL_DGELU) {
+        float u[4];
+        load4<T>(reinterpret_cast<const T*>(g.aux) + (long)m * g.ldaux + n, u, v4, nvalid);
+        if (g.aux2) store4<T>(reinterpret_cast<T*>(g.aux2) + (long)m * g.ldaux + n, v, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_d1(u[e]);
+      }
+      if (g.residual) {
+        float r[4];
+        load4<T>(reinterpret_cast<const T*>(g.residual) + (long)m * g.ldr + n, r, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      TC* cp = Cp + (long)m * g.ldc + n;
+      if (g.beta != 0.f) {
+        float c0[4];
+        load4<TC>(cp, c0, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += g.beta * c0[e];
+      }
+      store4<TC>(cp, v, v4, nvalid);
+    }
+  }
+}
+
+template <typename T, typename TC>
+int launch_layout(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, dim3(NTHREADS), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, true, false>), grid, dim3(NTHREADS), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, dim3(NTHREADS), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, dim3(NTHREADS), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return PG_ERR_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->batch_inner <= 0) return PG_ERR_ARG;
+  if (d->batch % d->batch_inner) return PG_ERR_ARG;
+  const int epc = d->dtype == PG_BF16 ? 8 : 4;
+  // 16-byte chunk loads: leading dimensions and batch strides must keep chunks aligned.
+  if (d->lda % epc || d->ldb % epc || d->sAo % epc || d->sAi % epc || d->sBo % epc || d->sBi % epc) return PG_ERR_ALIGN;
+  if (((uintptr_t)d->A | (uintptr_t)d->B) & 15) return PG_ERR_ALIGN;
+  if (d->a_kmajor) { if (d->lda < ((d->K + epc - 1) / epc) * epc) return PG_ERR_ARG; }
+  else { if (d->M % epc || d->M < epc || d->lda < d->M) return PG_ERR_ARG; }
+  if (d->b_kmajor) { if (d->ldb < ((d->K + epc - 1) / epc) * epc) return PG_ERR_ARG; }
+  else { if (d->N % epc || d->N < epc || d->ldb < d->N) return PG_ERR_ARG; }
+  if ((d->residual || d->aux) && d->batch != 1) return PG_ERR_ARG;
+  if (d->act == PG_ACT_MUL_DGELU && !d->aux) return PG_ERR_ARG;
+  if (d->c_dtype != PG_F32 && d->c_dtype != d->dtype) return PG_ERR_ARG;
+
+  GemmArgs a;
+  a.A = d->A; a.B = d->B; a.C = d->C;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+  a.batch_inner = d->batch_inner;
+  a.sAo = d->sAo; a.sAi = d->sAi; a.sBo = d->sBo; a.sBi = d->sBi; a.sCo = d->sCo; a.sCi = d->sCi;
+  a.alpha = d->alpha; a.beta = d->beta;
+  a.bias = d->bias; a.residual = d->residual; a.ldr = d->ldr; a.aux = d->aux; a.ldaux = d->ldaux;
+  a.aux2 = d->act == PG_ACT_MUL_DGELU ? d->aux2 : nullptr;
+  a.act = d->act;
+  const int csz = d->c_dtype == PG_F32 ? 4 : 2;
+  const int tsz = d->dtype == PG_F32 ? 4 : 2;
+  bool vec = (d->ldc % 4 == 0) && (d->sCo % 4 == 0) && (d->sCi % 4 == 0) && (((uintptr_t)d->C) % (4 * csz) == 0);
+  if (d->residual) vec = vec && (d->ldr % 4 == 0) && (((uintptr_t)d->residual) % (4 * tsz) == 0);
+  if (d->aux) vec = vec && (d->ldaux % 4 == 0) && (((uintptr_t)d->aux) % (4 * tsz) == 0);
+  if (a.aux2) vec = vec && (((uintptr_t)a.aux2) % (4 * tsz) == 0);
+  a.vec_ok = vec ? 1 : 0;
+
+  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == PG_BF16) {
+    if (d->c_dtype == PG_F32) return launch_layout<bf16_t, float>(d, a, grid, st);
+    return launch_layout<bf16_t, bf16_t>(d, a, grid, st);
+  } else if (d->dtype == PG_F32) {
+    return launch_layout<float, float>(d, a, grid, st);
+  }
+  return PG_ERR_ARG;
+}

@@ -1,0 +1,188 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per kernel entry point).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+arithmetic step is a call into libprotgen_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import PG_ACT_GELU, PG_ACT_MUL_DGELU, PG_ACT_NONE, PG_BF16, PG_F32, check, lib
+
+_DT = {torch.float32: PG_F32, torch.bfloat16: PG_BF16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dtype}; use torch.float32 or torch.bfloat16")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("protgen-gan_amd kernels need tensors on a HIP device (there is no CPU path)")
+
+
+def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alpha=1.0, beta=0.0, bias=None,
+         residual=None, act=PG_ACT_NONE, aux=None, aux2=None):
+    """2-D GEMM.  A is [M,K] (a_kmajor) or [K,M]; B is [N,K] (b_kmajor) or [K,N]."""
+    _need_cuda(A, B)
+    M, K = (A.shape if a_kmajor else (A.shape[1], A.shape[0]))
+    N, K2 = (B.shape if b_kmajor else (B.shape[1], B.shape[0]))
+    assert K == K2, (A.shape, B.shape)
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    out_dtype = out_dtype or A.dtype
+    if C_out is None:
+        C_out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    d.dtype, d.c_dtype = dt_code(A.dtype), dt_code(C_out.dtype)
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), C_out.stride(0)
+    d.batch, d.batch_inner = 1, 1
+    d.alpha, d.beta = alpha, beta
+    d.bias = ptr(bias)
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(0)
+    if aux2 is not None:
+        d.aux2 = aux2.data_ptr()
+    d.act = act
+    check(lib.pg_gemm(C.byref(d), stream()), "pg_gemm")
+    return C_out
+
+
+def layernorm(x, gamma, beta, eps):
+    y = torch.empty_like(x)
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    check(lib.pg_layernorm(dt_code(x.dtype), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(), rows,
+                           H, stream()), "pg_layernorm")
+    return y
+
+
+def _ln_partial(rows, H, device):
+    return torch.empty(2 * H * lib.pg_ln_partial_rows(rows), dtype=torch.float32, device=device)
+
+
+def layernorm_bwd(x, dy, gamma, eps, dgamma=None, dbeta=None):
+    dx = torch.empty_like(x)
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    part = _ln_partial(rows, H, x.device) if (dgamma is not None or dbeta is not None) else None
+    check(lib.pg_layernorm_bwd(dt_code(x.dtype), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), eps, dx.data_ptr(),
+                               ptr(dgamma), ptr(dbeta), ptr(part), rows, H, stream()), "pg_layernorm_bwd")
+    return dx
+
+
+def layernorm_jvp(x, xdot, gamma, eps):
+    y = torch.empty_like(x)
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    check(lib.pg_layernorm_jvp(dt_code(x.dtype), x.data_ptr(), xdot.data_ptr(), gamma.data_ptr(), eps, y.data_ptr(),
+                               rows, H, stream()), "pg_layernorm_jvp")
+    return y
+
+
+def layernorm_bwd2(x, xdot, gy, ybar, gamma, eps, dgamma=None, dbeta=None):
+    xbar = torch.empty_like(x)
+    rows, H = x.numel() // x.shape[-1], x.shape[-1]
+    part = _ln_partial(rows, H, x.device) if (dgamma is not None or dbeta is not None) else None
+    check(lib.pg_layernorm_bwd2(dt_code(x.dtype), x.data_ptr(), xdot.data_ptr(), gy.data_ptr(), ptr(ybar),
+                                gamma.data_ptr(), eps, xbar.data_ptr(), ptr(dgamma), ptr(dbeta), ptr(part), rows, H,
+                                stream()), "pg_layernorm_bwd2")
+    return xbar
+
+
+def gelu_bwd2(u, udot, ggu, gubar):
+    out = torch.empty_like(u)
+    check(lib.pg_gelu_bwd2(dt_code(u.dtype), u.data_ptr(), ptr(udot), ptr(ggu), gubar.data_ptr(), out.data_ptr(),
+                           u.numel(), stream()), "pg_gelu_bwd2")
+    return out
+
+
+def colsum_acc(dY, db):
+    rows, N = dY.shape
+    check(lib.pg_colsum_acc(dt_code(dY.dtype), dY.data_ptr(), dY.stride(0), rows, N, db.data_ptr(), stream()),
+          "pg_colsum_acc")
+    return db
+
+
+def score_ld(S: int) -> int:
+    return lib.pg_score_ld(S)
+
+
+def softmax_fwd(scores, mask, B, heads, S, dtype):
+    P = torch.empty(B * heads, S, score_ld(S), dtype=dtype, device=scores.device)
+    check(lib.pg_softmax_fwd(dt_code(dtype), scores.data_ptr(), ptr(mask), P.data_ptr(), B, heads, S, stream()),
+          "pg_softmax_fwd")
+    return P
+
+
+def softmax_bwd(dP, P, S):
+    dS = torch.empty_like(P)
+    check(lib.pg_softmax_bwd(dt_code(P.dtype), dP.data_ptr(), P.data_ptr(), dS.data_ptr(), P.shape[0], S, stream()),
+          "pg_softmax_bwd")
+    return dS
+
+
+def softmax_jvp(Sdot, P, S):
+    Sd, Pd = torch.empty_like(P), torch.empty_like(P)
+    check(lib.pg_softmax_jvp(dt_code(P.dtype), Sdot.data_ptr(), P.data_ptr(), Sd.data_ptr(), Pd.data_ptr(), P.shape[0],
+                             S, stream()), "pg_softmax_jvp")
+    return Sd, Pd
+
+
+def softmax_bwd2(P, Sdot, gP, X, S):
+    Sbar, Pd = torch.empty_like(P), torch.empty_like(P)
+    check(lib.pg_softmax_bwd2(dt_code(P.dtype), P.data_ptr(), Sdot.data_ptr(), gP.data_ptr(), X.data_ptr(),
+                              Sbar.data_ptr(), Pd.data_ptr(), P.shape[0], S, stream()), "pg_softmax_bwd2")
+    return Sbar, Pd
+
+
+def mlm_decode(t, word, bias):
+    T, H = t.shape
+    V = word.shape[0]
+    logits = torch.empty(T, V, dtype=torch.float32, device=t.device)
+    check(lib.pg_mlm_decode(dt_code(t.dtype), t.data_ptr(), word.data_ptr(), bias.data_ptr(), logits.data_ptr(), T, H,
+                            V, stream()), "pg_mlm_decode")
+    return logits
+
+
+def sample_tokens(logits, noise, temperature: float):
+    T, V = logits.shape
+    pred = torch.empty(T, dtype=torch.int64, device=logits.device)
+    conf = torch.empty(T, dtype=torch.float32, device=logits.device)
+    check(lib.pg_sample_tokens(logits.data_ptr(), noise.data_ptr(), float(temperature), T, V, pred.data_ptr(),
+                               conf.data_ptr(), stream()), "pg_sample_tokens")
+    return pred, conf
+
+
+def commit_topk(ids, pred, conf, keep_percent: float, fill_all: bool, mask_id=4, pad_id=0, cls_id=2, sep_id=3,
+                counts=None):
+    B, S = ids.shape
+    assert ids.is_contiguous() and ids.dtype == torch.int64
+    check(lib.pg_commit_topk(ids.data_ptr(), pred.data_ptr(), conf.data_ptr(), B, S, float(keep_percent), int(fill_all),
+                             mask_id, pad_id, cls_id, sep_id, ptr(counts), stream()), "pg_commit_topk")
+    return ids
+
+
+def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    check(lib.pg_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(shadow), p.numel(), lr, beta1, beta2,
+                       eps, wd, step, grad_scale, stream()), "pg_adamw")
+
+
+def cast_bf16(src, dst):
+    check(lib.pg_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream()), "pg_cast_bf16")

@@ -1,0 +1,395 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the C ABI
+(ctypes), against closed-form CPU statements (tests/kernel_specs.py, themselves checked
+against autograd on the CPU) or the oracle's functions.  Tolerances: fp32 kernels 2e-5
+relative to the tensor scale (exact fp32 FMA chains, different summation order than the
+CPU); bf16 kernels 2e-2 (inputs rounded to bf16 first, so only accumulation order and the
+output rounding differ)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import protbert_cpu as O  # noqa: E402
+from tests import kernel_specs as K  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import pgload
+    return pgload.load()
+
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+def close(got, ref, dtype, scale=None, mult=1.0):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    err = float((got - ref).abs().max())
+    assert err <= mult * tol(dtype) * max(s, 1e-6), f"max err {err:.3e} vs scale {s:.3e}"
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, gen=None):
+    """Random data already representable in `dtype` (so CPU fp64 references see the same inputs)."""
+    t = torch.randn(*shape, generator=gen) * scale
+    return t.to(dtype).to(torch.float32)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_exact_layouts(pg, dtype, ak, bk):
+    """Small-integer operands: every product and partial sum is exact in bf16/fp32, so any
+    fragment-layout or transposed-read mistake shows as a wrong integer.  A and B are
+    asymmetric; sizes leave ragged M/N/K tails."""
+    g = torch.Generator().manual_seed(1)
+    epc = 4 if dtype == torch.float32 else 8
+    M, N, K = 136 + epc, 200, 72 + epc
+    if not ak:
+        M = 144
+    if not bk:
+        N = 208
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[:, 0] += torch.arange(M) % 5
+    B[:, 1] -= torch.arange(N) % 7
+    ref = A.double() @ B.double().T
+    Ad = (A if ak else A.T.contiguous()).to(dtype).to(DEV)
+    Bd = (B if bk else B.T.contiguous()).to(dtype).to(DEV)
+    out = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
+    assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(pg, dtype):
+    g = torch.Generator().manual_seed(2)
+    M, N, Kd = 200, 264, 320
+    A, B = rnd(M, Kd, dtype=dtype, gen=g), rnd(N, Kd, dtype=dtype, scale=0.05, gen=g)
+    bias = torch.randn(N, generator=g)
+    res = rnd(M, N, dtype=dtype, gen=g)
+    Ad, Bd = A.to(dtype).to(DEV), B.to(dtype).to(DEV)
+    base = A.double() @ B.double().T
+    # bias + residual
+    out = pg.ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(dtype).to(DEV))
+    close(out, base + bias.double() + res.double(), dtype)
+    # bias + GELU with the pre-activation stored
+    aux = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = pg.ops.gemm(Ad, Bd, bias=bias.to(DEV), act=pg._lib.PG_ACT_GELU, aux=aux)
+    pre = base + bias.double()
+    close(aux, pre, dtype)
+    close(out, K.gelu(pre), dtype)
+    # multiply by gelu'(U), storing the unmultiplied value
+    U = rnd(M, N, dtype=dtype, gen=g)
+    aux2 = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = pg.ops.gemm(Ad, Bd, act=pg._lib.PG_ACT_MUL_DGELU, aux=U.to(dtype).to(DEV), aux2=aux2)
+    close(aux2, base, dtype)
+    close(out, base * K.gelu_d1(U.double()), dtype)
+    # alpha / beta accumulation into an fp32 C (the weight-gradient form)
+    C0 = torch.randn(M, N, generator=g)
+    Cd = C0.clone().to(DEV)
+    pg.ops.gemm(Ad, Bd, Cd, alpha=0.5, beta=1.0)
+    close(Cd, C0.double() + 0.5 * base, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_weight_gradient_shape(pg, dtype):
+    """dW = dY^T X with a token count that is not a multiple of the k tile."""
+    g = torch.Generator().manual_seed(3)
+    T, No, Ni = 328, 192, 128
+    dY, X = rnd(T, No, dtype=dtype, gen=g), rnd(T, Ni, dtype=dtype, gen=g)
+    out = pg.ops.gemm(dY.to(dtype).to(DEV), X.to(dtype).to(DEV), a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    close(out, dY.double().T @ X.double(), dtype)
+
+
+def test_gemm_rejects_bad_arguments(pg):
+    with pytest.raises(pg._lib.PgError):  # fp32 leading dimension not a multiple of 4 elements
+        pg.ops.gemm(torch.zeros(64, 34, device=DEV), torch.zeros(64, 34, device=DEV))
+    flat = torch.zeros(64 * 36 + 1, device=DEV)
+    with pytest.raises(pg._lib.PgError):  # operand not 16-byte aligned
+        pg.ops.gemm(flat[1:].view(64, 36), torch.zeros(64, 36, device=DEV))
+    with pytest.raises(pg._lib.PgError):  # m-major operand whose free extent is not a multiple of the chunk
+        pg.ops.gemm(torch.zeros(36, 66, device=DEV)[:, :62], torch.zeros(64, 36, device=DEV), a_kmajor=False)
+
+
+# ----------------------------------------------------------------------------- LayerNorm family
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [64, 128, 256, 1024])
+def test_layernorm_family(pg, dtype, H):
+    g = torch.Generator().manual_seed(4)
+    R, eps = 37, 1e-12
+    x, xdot, gy, ybar = (rnd(R, H, dtype=dtype, gen=g) for _ in range(4))
+    gam = 1 + 0.1 * torch.randn(H, generator=g)
+    bet = 0.1 * torch.randn(H, generator=g)
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    gd, bd = gam.to(DEV), bet.to(DEV)
+    close(pg.ops.layernorm(d(x), gd, bd, eps), K.ln_fwd(x.double(), gam.double(), bet.double(), eps), dtype)
+    dg = torch.full((H,), 0.5, device=DEV)
+    db = torch.full((H,), -0.25, device=DEV)
+    dx = pg.ops.layernorm_bwd(d(x), d(gy), gd, eps, dg, db)
+    rdx, rdg, rdb = K.ln_bwd(x.double(), gy.double(), gam.double(), eps)
+    close(dx, rdx, dtype)
+    close(dg, rdg + 0.5, torch.float32, mult=10)
+    close(db, rdb - 0.25, torch.float32, mult=10)
+    close(pg.ops.layernorm_jvp(d(x), d(xdot), gd, eps), K.ln_jvp(x.double(), xdot.double(), gam.double(), eps), dtype)
+    for yb in (ybar, None):
+        dg.zero_()
+        db.zero_()
+        xb = pg.ops.layernorm_bwd2(d(x), d(xdot), d(gy), None if yb is None else d(yb), gd, eps, dg, db)
+        rx, rg, rb = K.ln_bwd2(x.double(), xdot.double(), gy.double(), None if yb is None else yb.double(), gam.double(), eps)
+        close(xb, rx, dtype, mult=2)
+        close(dg, rg, torch.float32, mult=20)
+        close(db, rb, torch.float32, scale=max(float(rb.abs().max()), 1.0), mult=20)
+
+
+def test_layernorm_many_rows(pg):
+    """More rows than partial-sum slots: the grid-stride path of the parameter gradients."""
+    g = torch.Generator().manual_seed(5)
+    R, H, eps = 2500, 128, 1e-12
+    x, gy = torch.randn(R, H, generator=g), torch.randn(R, H, generator=g)
+    gam = 1 + 0.1 * torch.randn(H, generator=g)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx = pg.ops.layernorm_bwd(x.to(DEV), gy.to(DEV), gam.to(DEV), eps, dg, db)
+    rdx, rdg, rdb = K.ln_bwd(x.double(), gy.double(), gam.double(), eps)
+    close(dx, rdx, torch.float32)
+    close(dg, rdg, torch.float32, mult=10)
+    close(db, rdb, torch.float32, mult=10)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gelu_bwd2_and_colsum(pg, dtype):
+    g = torch.Generator().manual_seed(6)
+    u, udot, ggu, gub = (rnd(50, 96, dtype=dtype, gen=g) for _ in range(4))
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    close(pg.ops.gelu_bwd2(d(u), d(udot), d(ggu), d(gub)), K.gelu_bwd2(u.double(), udot.double(), ggu.double(), gub.double()), dtype)
+    close(pg.ops.gelu_bwd2(d(u), None, None, d(gub)), K.gelu_bwd2(u.double(), None, None, gub.double()), dtype)
+    dY = rnd(777, 200, dtype=dtype, gen=g)
+    db = torch.ones(200, device=DEV)
+    pg.ops.colsum_acc(d(dY), db)
+    close(db, dY.double().sum(0) + 1, torch.float32, mult=20)
+
+
+# ----------------------------------------------------------------------------- softmax family
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [40, 64, 200])
+def test_softmax_family(pg, dtype, S):
+    g = torch.Generator().manual_seed(7)
+    B, nh = 2, 2
+    Z, ld = B * nh, pg.ops.score_ld(S)
+    sc = torch.zeros(Z, S, ld)
+    sc[:, :, :S] = torch.randn(Z, S, S, generator=g) * 2
+    sc[:, :, S:] = float("nan")  # padding columns must never be read
+    mask = torch.ones(B, S)
+    mask[0, S - 7:] = 0
+    mask[1, 3] = 0
+    ext = O.extended_mask(mask, torch.float64)  # [B,1,1,S]
+    ref = torch.softmax(sc[:, :, :S].double().view(B, nh, S, S) + ext, -1).view(Z, S, S)
+    P = pg.ops.softmax_fwd(sc.to(DEV), mask.to(DEV), B, nh, S, dtype)
+    close(P[:, :, :S], ref, dtype)
+    assert float(P[:, :, S:].float().abs().max() if ld > S else 0.0) == 0.0
+    assert float(P.float()[0, :, S - 7:S].abs().max()) == 0.0  # masked keys get exactly zero
+    # backward / tangent / second order use the device's own P so only the new op is measured
+    Pd = P.float().cpu().double()[:, :, :S]
+    dP, Sdot, gP, X = (torch.randn(Z, S, S, generator=g) for _ in range(4))
+
+    def pad(t):
+        o = torch.full((Z, S, ld), float("nan"))
+        o[:, :, :S] = t
+        return o.to(DEV)
+
+    dS = pg.ops.softmax_bwd(pad(dP), P, S)
+    close(dS[:, :, :S], K.softmax_bwd(dP.double(), Pd), dtype)
+    Sd_out, Pdot = pg.ops.softmax_jvp(pad(Sdot), P, S)
+    close(Pdot[:, :, :S], K.softmax_jvp(Sdot.double(), Pd), dtype)
+    close(Sd_out[:, :, :S], Sdot.double(), dtype)
+    Sd_in = Sd_out.float().cpu().double()[:, :, :S]
+    Sbar, Pdot2 = pg.ops.softmax_bwd2(P, Sd_out, pad(gP), pad(X), S)
+    rS, rP = K.softmax_bwd2(Pd, Sd_in, gP.double(), X.double())
+    close(Sbar[:, :, :S], rS, dtype, mult=2)
+    close(Pdot2[:, :, :S], rP, dtype)
+    if ld > S:
+        assert float(Sbar[:, :, S:].float().abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- sampler
+def test_mlm_decode_sample_commit(pg):
+    g = torch.Generator().manual_seed(8)
+    B, S, H, V = 3, 50, 128, 30
+    t = torch.randn(B * S, H, generator=g)
+    word = torch.randn(V, H, generator=g) * 0.3
+    bias = torch.randn(V, generator=g) * 0.1
+    for dtype in DTYPES:
+        td = t.to(dtype)
+        logits = pg.ops.mlm_decode(td.to(DEV), word.to(DEV), bias.to(DEV))
+        close(logits, td.double() @ word.double().T + bias.double(), torch.float32, mult=4)
+    logits = (t @ word.T + bias).view(B, S, V)
+    noise = O.draw_noise(B * S, V, g)
+    for temp in (1.0, 0.83):
+        _, pred_ref, conf_ref = O.sample_from_logits(logits, temp, noise)
+        pred, conf = pg.ops.sample_tokens(logits.view(-1, V).to(DEV), noise.to(DEV), temp)
+        assert torch.equal(pred.cpu().view(B, S), pred_ref)
+        np.testing.assert_allclose(conf.cpu().view(B, S).numpy(), conf_ref.numpy(), rtol=2e-5)
+        # commit: every branch of models.py:35-63 (row without masks, fill-all, keep_percent, k clamps)
+        ids = torch.full((B, S), O.PAD, dtype=torch.long)
+        ids[:, 0] = O.CLS
+        ids[0, 1:41] = O.MASK
+        ids[0, 41] = O.SEP
+        ids[1, 1:31] = torch.randint(5, 25, (30,), generator=g)
+        ids[1, 31] = O.SEP  # no mask at all
+        ids[2, 1:48] = torch.randint(5, 25, (47,), generator=g)
+        ids[2, [5, 9, 33]] = O.MASK  # fewer masks than keep_percent * meaningful
+        ids[2, 48] = O.SEP
+        for rate in (1.0, 0.5, 0.10000000000000014, 0.1, 1.3877787807814457e-16, None):
+            ref_ids = ids.clone()
+            committed = O.commit_step(ref_ids, pred_ref, conf_ref, 0.1, rate)
+            got = ids.clone().to(DEV)
+            counts = torch.zeros(B, 2, dtype=torch.int32, device=DEV)
+            fill_all = rate is not None and rate <= 0.1
+            pg.ops.commit_topk(got, pred, conf_ref.reshape(-1).to(DEV), 0.1, fill_all, counts=counts)
+            assert torch.equal(got.cpu(), ref_ids), f"rate {rate}"
+            assert counts[:, 0].cpu().tolist() == committed
+            assert counts[:, 1].cpu().tolist() == (ref_ids == O.MASK).sum(1).tolist()
+
+
+def test_commit_ties_lowest_index(pg):
+    ids = torch.tensor([[O.CLS] + [O.MASK] * 20 + [O.SEP]], device=DEV)
+    pred = torch.full((1, 22), 7, dtype=torch.long, device=DEV)
+    conf = torch.full((1, 22), 0.25, device=DEV)
+    pg.ops.commit_topk(ids, pred.view(-1), conf.view(-1), 0.1, False)
+    assert ids[0].tolist() == [O.CLS, 7, 7] + [O.MASK] * 18 + [O.SEP]  # int(0.1*20) = 2 lowest positions
+
+
+# ----------------------------------------------------------------------------- critic head
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_forward_backward_tangent(pg, dtype):
+    from protgen_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(9)
+    B, S, H = 3, 5, 128
+    Cw = O.init_classifier(H, seed=11)
+    hid = rnd(B, S, H, dtype=dtype, gen=g)
+    flat = torch.cat([Cw[f"{k}.{n}"].reshape(-1) for k in (0, 2, 4, 6) for n in ("weight", "bias")]).to(DEV)
+    assert flat.numel() == lib.pg_head_total(H)
+    hd = hid.to(dtype).to(DEV)
+    scores = torch.empty(B, 1, device=DEV)
+    stash = torch.empty(B, lib.pg_head_stash_floats(H), device=DEV)
+    st = pg.ops.stream()
+    dt = pg.ops.dt_code(dtype)
+    assert lib.pg_head_forward(dt, hd.data_ptr(), S * H, flat.data_ptr(), B, H, scores.data_ptr(), stash.data_ptr(), st) == 0
+    # CPU reference with autograd (fp64)
+    Cd = {k: v.double().requires_grad_(True) for k, v in Cw.items()}
+    x = hid[:, 0, :].double().requires_grad_(True)
+    s_ref = O.classifier(Cd, x)
+    close(scores, s_ref, torch.float32, mult=4)
+    w = torch.tensor([0.7, -1.3, 0.4])
+    (s_ref.squeeze(1) * w.double()).sum().backward()
+    ghead = torch.zeros_like(flat)
+    dh = torch.zeros(B, S, H, dtype=dtype, device=DEV)
+    assert lib.pg_head_backward(dt, flat.data_ptr(), stash.data_ptr(), w.to(DEV).data_ptr(), B, H, ghead.data_ptr(),
+                                dh.data_ptr(), S * H, st) == 0
+    close(dh[:, 0, :], x.grad, dtype)
+    assert float(dh[:, 1:, :].float().abs().max()) == 0.0
+    gref = torch.cat([Cd[f"{k}.{n}"].grad.reshape(-1) for k in (0, 2, 4, 6) for n in ("weight", "bias")])
+    close(ghead, gref, torch.float32, mult=8)
+    # tangent + gradient of sum(sdot) w.r.t. the head parameters
+    xdot = rnd(B, S, H, dtype=dtype, gen=g)
+    Cd2 = {k: v.double().requires_grad_(True) for k, v in Cw.items()}
+    x2 = hid[:, 0, :].double().requires_grad_(True)
+    s2 = O.classifier(Cd2, x2).sum()
+    gx, = torch.autograd.grad(s2, x2, create_graph=True)
+    sur = (gx * xdot[:, 0, :].double()).sum()
+    sur.backward()
+    ghead.zero_()
+    tst = torch.empty_like(stash)
+    sdot = torch.empty(B, device=DEV)
+    assert lib.pg_head_jvp_grad(dt, flat.data_ptr(), stash.data_ptr(), xdot.to(dtype).to(DEV).data_ptr(), S * H, B, H, 2.0,
+                                ghead.data_ptr(), tst.data_ptr(), sdot.data_ptr(), st) == 0
+    gref2 = torch.cat([(Cd2[f"{k}.{n}"].grad if Cd2[f"{k}.{n}"].grad is not None else torch.zeros_like(Cd2[f"{k}.{n}"])).reshape(-1)
+                       for k in (0, 2, 4, 6) for n in ("weight", "bias")])
+    close(ghead, 2.0 * gref2, torch.float32, mult=8)
+    close(sdot.sum(), sur.detach(), torch.float32, mult=8)
+
+
+# ----------------------------------------------------------------------------- GP reductions, interpolation, scatter, AdamW
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gp_reductions_and_interpolation(pg, dtype):
+    from protgen_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(10)
+    B, S, H = 3, 24, 64
+    gr = rnd(B, S, H, dtype=dtype, scale=0.05, gen=g)
+    mask = (torch.rand(B, S, generator=g) > 0.3).float()
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    st, dt = pg.ops.stream(), pg.ops.dt_code(dtype)
+    norms = torch.empty(B, device=DEV)
+    gp = torch.empty((), device=DEV)
+    assert lib.pg_gp_norms(dt, d(gr).data_ptr(), mask.to(DEV).data_ptr(), B, S, H, norms.data_ptr(), gp.data_ptr(), st) == 0
+    n_ref = (gr.double() * mask[..., None].double()).flatten(1).norm(dim=1)
+    close(norms, n_ref, torch.float32, mult=4)
+    close(gp, ((n_ref - 1) ** 2).mean(), torch.float32, mult=4)
+    v = torch.empty(B, S, H, dtype=dtype, device=DEV)
+    scale = torch.tensor(5.0, device=DEV)
+    assert lib.pg_gp_direction(dt, d(gr).data_ptr(), mask.to(DEV).data_ptr(), norms.data_ptr(), B, S, H, scale.data_ptr(),
+                               v.data_ptr(), None, st) == 0
+    v_ref = 5.0 * (2.0 / B) * ((n_ref - 1) / n_ref)[:, None, None] * gr.double() * mask[..., None].double()
+    close(v, v_ref, dtype)
+    er, ef = rnd(B, S, H, dtype=dtype, gen=g), rnd(B, S, H, dtype=dtype, gen=g)
+    alpha = torch.rand(B, generator=g)
+    x = torch.empty(B, S, H, dtype=dtype, device=DEV)
+    assert lib.pg_interpolate(dt, d(er).data_ptr(), d(ef).data_ptr(), alpha.to(DEV).data_ptr(), x.data_ptr(), B, S * H, st) == 0
+    a = alpha.double()[:, None, None]
+    close(x, a * er.double() + (1 - a) * ef.double(), dtype)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    assert lib.pg_interpolate_bwd(dt, d(er).data_ptr(), alpha.to(DEV).data_ptr(), o1.data_ptr(), o2.data_ptr(), B, S * H, st) == 0
+    close(o1, a * er.double(), dtype)
+    close(o2, (1 - a) * er.double(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_forward_and_scatter(pg, dtype):
+    from protgen_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(11)
+    B, S, H, V = 2, 19, 128, 30
+    word, pos, typ = torch.randn(V, H, generator=g), torch.randn(40, H, generator=g), torch.randn(2, H, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    ids = torch.randint(0, V, (B, S), generator=g)
+    st, dt = pg.ops.stream(), pg.ops.dt_code(dtype)
+    out = torch.empty(B, S, H, dtype=dtype, device=DEV)
+    esum = torch.empty_like(out)
+    dw, dp, dty, dg, db, di = (t.to(DEV) for t in (word, pos, typ, gam, bet, ids))
+    assert lib.pg_embed_ln2(dt, di.data_ptr(), dw.data_ptr(), dp.data_ptr(), dty.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                            1e-12, out.data_ptr(), esum.data_ptr(), B, S, H, st) == 0
+    sref = (word[ids] + typ[0]) + pos[:S][None]
+    close(esum, sref, dtype)
+    close(out, K.ln_fwd(esum.float().cpu().double(), gam.double(), bet.double(), 1e-12), dtype)
+    dsum = rnd(B, S, H, dtype=dtype, gen=g)
+    gw, gpz, gt = torch.zeros(V, H, device=DEV), torch.zeros(40, H, device=DEV), torch.zeros(H, device=DEV)
+    assert lib.pg_embed_scatter(dt, dsum.to(dtype).to(DEV).data_ptr(), di.data_ptr(), gw.data_ptr(), gpz.data_ptr(),
+                                gt.data_ptr(), B, S, H, st) == 0
+    rw = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids.reshape(-1), dsum.double().reshape(-1, H))
+    close(gw, rw, torch.float32, mult=8)
+    rp = torch.zeros(40, H, dtype=torch.float64)
+    rp[:S] = dsum.double().sum(0)
+    close(gpz, rp, torch.float32, mult=8)
+    close(gt, dsum.double().sum((0, 1)), torch.float32, mult=8)
+
+
+def test_adamw_and_casts(pg):
+    g = torch.Generator().manual_seed(12)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g)
+        O.adamw_step(p, gr, m, v, step, 3e-3, wd=0.01)
+        pg.ops.adamw(pd, gr.to(DEV), md, vd, sh, 3e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    np.testing.assert_allclose(pd.cpu().numpy(), p.numpy(), rtol=2e-6, atol=2e-7)
+    assert torch.equal(sh.cpu(), pd.cpu().to(torch.bfloat16))
