@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""ProtBERT GAN benchmark on MI355X.
+
+A step is one iteration of the reference's blind-mode training loop
+(fully_masked_train.py:284-352) at BASELINE.json's configs[1]: n_critic = 8 critic updates
+(each: 10-iteration fill of a fresh fake batch of 8 with the generator, gradient penalty with
+its double backward, real and fake scores, c_loss.backward(), AdamW) followed by one generator
+update (fill of 4 fakes, critic score, g_loss.backward()), len 512, bf16 compute with fp32
+master weights and accumulation, both ProtBERTs unfrozen, lambda_gp = 5.  Weights are the
+full-size ProtBERT architecture with seeded random values and the data are synthetic
+DNMT-length sequences (neither checkpoints nor the dataset ship with the reference).
+
+  python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torchrun)
+  python bench.py --mode generate                         (sequences/s of the fill loop)
+
+Prints one JSON line (rank 0).  `value` is summed over ranks (weak scaling: every rank runs
+the per-GPU step on its own data and the critic gradients are averaged over RCCL)."""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_BF16 = 2.5e15  # dense bf16 MFMA peak of MI355X (spec)
+VARIANT_NAMES = {8 + 2 + 1: "gemm_bf16_nt (X W^T, Q K^T)", 8 + 2 + 0: "gemm_bf16_nn (dY W, P V)",
+                 8 + 4 + 0: "gemm_bf16_tn_f32out (dW = dY^T X)", 8 + 0: "gemm_bf16_tn (dS^T Q, P^T dO)",
+                 8 + 4 + 2 + 1: "gemm_bf16_nt_f32out (scores)", 8 + 1: "gemm_bf16_tn_kB", 8 + 4 + 2: "gemm_bf16_nn_f32out",
+                 8 + 4 + 1: "gemm_bf16_tn_kB_f32out"}
+
+
+def f_enc(S, H=1024, I=4096, L=30):
+    return L * (2 * (4 * H * H + 2 * H * I) + 4 * S * H)
+
+
+def f_gen_tok(S, H=1024, V=30):
+    return f_enc(S) + 2 * H * H + 2 * H * V
+
+
+def f_c(B, S):
+    return B * S * f_enc(S) + B * 1343616
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["train", "generate"], default="train")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--gen-batch", type=int, default=4)
+    ap.add_argument("--n-critic", type=int, default=8)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--lambda-gp", type=float, default=5.0)
+    ap.add_argument("--layers", type=int, default=30, help="(debug only) fewer layers invalidates the number")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-sample", type=int, default=16)
+    args = ap.parse_args()
+
+    import pgload
+    pg = pgload.load()
+    from protgen_gan_amd import distributed as pgd
+    from protgen_gan_amd import train as pgt
+    from protgen_gan_amd._lib import lib
+
+    rank, local, world = pgd.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    cfg = pg.ProtBertConfig(num_hidden_layers=args.layers)
+    generator = pg.Generator(pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=dtype).init_random(seed=0))
+    torch.manual_seed(2)
+    critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=dtype).init_random(seed=1))
+    hp = pgt.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.seq, gen_batch_blind=args.gen_batch)
+    gen_opt = pg.AdamW(generator.parameters(), lr=5e-6, betas=(0.9, 0.999), weight_decay=0.01)
+    critic_opt = pg.AdamW(critic.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world)
+
+    rng = random.Random(1234 + rank)
+    torch.manual_seed(1234 + rank)
+    tgen = torch.Generator().manual_seed(1234 + rank)
+    scale = args.seq / 512.0
+    pool = [int(L * scale) for L in range(200, 501)]  # DNMT-length stand-in: uniform 200..500
+
+    if args.mode == "generate":
+        return bench_generate(args, pg, generator, pool, rng, rank, world, dev)
+
+    total = args.warmup + args.steps
+    real = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic)]
+            for _ in range(total)]
+
+    def one_step(i):
+        return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
+                                  grad_sync=sync if world > 1 else None)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    generator.fill_shapes.clear()
+    lib.pg_profile_begin(args.profile_sample)
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.warmup, total):
+        last = one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 48)()
+    nl = ctypes.c_int64(0)
+    lib.pg_profile_end(prof, ctypes.byref(nl))
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    c_loss, g_loss = float(last[0]), float(last[1])
+
+    # algorithmic FLOPs of the timed region on this rank
+    fill_flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
+    critic_flops = args.steps * args.n_critic * 12 * f_c(args.batch, args.seq)
+    gen_flops = args.steps * 3 * f_c(args.gen_batch, args.seq)
+    flops_step = (fill_flops + critic_flops + gen_flops) / args.steps
+    ms_step = dt / args.steps * 1e3
+
+    variants = []
+    for v in range(16):
+        n, fl, ms = prof[v * 3], prof[v * 3 + 1], prof[v * 3 + 2]
+        if n > 0:
+            variants.append({"kernel": VARIANT_NAMES.get(v, f"gemm_variant_{v}"), "sampled_launches": int(n),
+                             "avg_us": ms / n * 1e3, "tflops": fl / (ms * 1e-3) / 1e12, "time_share_of_gemm": ms})
+    tot_ms = sum(v["time_share_of_gemm"] for v in variants) or 1.0
+    for v in variants:
+        v["time_share_of_gemm"] = round(v["time_share_of_gemm"] / tot_ms, 4)
+    variants.sort(key=lambda v: -v["time_share_of_gemm"])
+    dom = variants[0] if variants else None
+    roofline = None
+    if dom:
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
+                    "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(dom["tflops"] * 1e12 / MFMA_PEAK_BF16, 4),
+                    "traffic": None, "avg_launch_us": round(dom["avg_us"], 2), "sampled_launches": dom["sampled_launches"],
+                    "gemm_launches_total": int(nl.value)}
+
+    out = {
+        "metric": "ProtBERT GAN train steps/s (gen+critic) & generated seqs/s, 1/2/4/8 GPUs",
+        "value": round(world * args.steps / dt, 5), "unit": "GAN steps/s (n_critic=8 critic updates + 1 generator update; summed over ranks)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head",
+                   "critic_batch": args.batch, "generator_batch": args.gen_batch, "seq_len": args.seq, "n_critic": args.n_critic,
+                   "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": "unfrozen",
+                   "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
+                   "weights": "ProtBERT architecture, seeded random init", "lengths": "uniform 200..500 (DNMT-length stand-in)"},
+        "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
+        "step_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 2),
+        "step_mfma_frac": round(flops_step / (dt / args.steps) / MFMA_PEAK_BF16, 4),
+        "c_loss": c_loss, "g_loss": g_loss,
+        "roofline": roofline, "gemm_variants": variants,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
+    """Generated sequences/s of generate.py's full mode (batch 64 per GPU, lengths from the pool)."""
+    from protgen_gan_amd import generate as gen_py
+    tok = pg.ProtTokenizer()
+    bs = 64
+    n = bs * max(1, args.steps)
+    gen_py.generate_full_mode_sequences(generator, tok, bs * max(1, args.warmup), pool, batch_size=bs, device=str(dev), rng_seed=7 + rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    generator.fill_shapes.clear()
+    t0 = time.perf_counter()
+    seqs = gen_py.generate_full_mode_sequences(generator, tok, n, pool, batch_size=bs, device=str(dev), rng_seed=42 + rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
+    out = {"metric": "generated sequences/s (generate.py full mode)", "value": round(world * n / dt, 3), "unit": "sequences/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "configs[3]-style mass generation, batch 64 per GPU, lengths uniform 200..500, 10 fill iterations",
+                      "sequences_per_rank": n, "parallelism": f"shard{world}"},
+           "mean_len": sum(len(s) for s in seqs) / len(seqs), "step_mfma_frac": round(flops / dt / MFMA_PEAK_BF16, 4)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a plain-PyTorch fp32 restatement of the reference path) timed on this
+    box's host cores on a bounded sample: one fill iteration and one critic update (GP double
+    backward + real + fake + backward + AdamW) at batch 1, len 512, full-size ProtBERT; the GAN
+    step time is composed linearly in batch and iteration counts."""
+    from oracle import protbert_cpu as O
+    torch.set_num_threads(min(torch.get_num_threads(), os.cpu_count() or 1))
+    cores = torch.get_num_threads()
+    c = O.BertCfg(num_hidden_layers=args.layers, max_position_embeddings=args.seq)
+    P = O.init_params(c, seed=0)
+    C = O.init_classifier(c.hidden_size, seed=2)
+    g = torch.Generator().manual_seed(0)
+    S = args.seq
+    ids, attn = O.build_fully_masked_batch([S - 2])
+    noise = O.draw_noise(S, c.vocab_size, g)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.generate_step(P, c, ids, attn, 1.0, 0.1, 1.0, noise)
+    t_fill = time.perf_counter() - t0
+    real = torch.randint(5, 25, (1, S), generator=g)
+    fake = torch.randint(5, 25, (1, S), generator=g)
+    ones = torch.ones(1, S, dtype=torch.long)
+    t0 = time.perf_counter()
+    loss, gp, rs, fs, grads = O.critic_step_grads(P, C, c, real, fake, ones, ones, torch.rand(1, 1, 1, generator=g), args.lambda_gp)
+    k = "protbert.bert.encoder.layer.0.output.dense.weight"
+    p, gr = P[k[len("protbert."):]].clone(), grads[k]
+    t1 = time.perf_counter()
+    O.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, 5e-5)
+    t_adam = (time.perf_counter() - t1) * (420.6e6 / p.numel())
+    t_critic = time.perf_counter() - t0 - (time.perf_counter() - t1) + t_adam
+    t_step = args.n_critic * (args.batch * t_critic + 10 * args.batch * t_fill) + (10 * args.gen_batch * t_fill + args.gen_batch * t_critic / 4)
+    return {"value": round(1.0 / t_step, 6), "unit": "GAN steps/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle/protbert_cpu.py fp32 on {cores} host threads: 1 fill iteration B=1 S={S} ({t_fill:.2f} s) + 1 critic update "
+                       f"B=1 S={S} incl. GP double backward and AdamW ({t_critic:.2f} s); GAN step composed as "
+                       f"n_critic*(B*critic + 10*B*fill) + (10*Bg*fill + Bg*critic/4) = {t_step:.0f} s")}
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,13 @@ typedef struct {
   int act;
 } pg_gemm_desc;
 int pg_gemm(const pg_gemm_desc* d, void* stream);
+/* Measurement aid (no reference counterpart): time every `sample_every`-th pg_gemm launch
+ * with HIP events on its own stream.  pg_profile_end synchronises those events, stops the
+ * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
+ * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
+ * process-global and not thread-safe. */
+int pg_profile_begin(int sample_every);
+int pg_profile_end(double* out, int64_t* total_launches);
 
 /* ------------------------------------------------------------------ row-wise kernels (K3/K4/K9/K10)
  * H must be 64, 128, 256, 512 or 1024 (one wavefront per row).                          */

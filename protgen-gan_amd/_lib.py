@@ -61,6 +61,8 @@ SIGNATURES = {
     "pg_head_total": (i64, [i32]),
     "pg_head_offset": (i64, [i32, i32, i32]),
     "pg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "pg_profile_begin": (i32, [i32]),
+    "pg_profile_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pg_embed_ln": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
     "pg_embed_ln2": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "pg_layernorm": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp]),

@@ -16,10 +16,17 @@
 // ds_read_b128; m-major bf16 fragments with the transposing ds_read_b64_tr_b16.
 // The MFMA is issued with the operands swapped (D = Bt * At) so that a lane owns four
 // consecutive n of one output row, which makes every epilogue access an 8/16-byte vector.
+#include <vector>
 #include "pg_common.h"
 #include "protgen_hip.h"
 
 namespace {
+
+// Optional sampled timing of GEMM launches with HIP events on the launch stream (used by the
+// benchmark to report achieved FLOP/s per kernel variant without a profiler attached).
+struct ProfEntry { hipEvent_t a, b; int variant; double flops; };
+struct ProfState { int every = 0; long counter = 0; long launches = 0; std::vector<ProfEntry> entries; };
+ProfState g_prof;
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
@@ -56,7 +63,10 @@ struct GemmArgs {
 };
 
 // ---- global -> register staging of one operand tile -------------------------------------
-template <typename T, bool KMAJOR>
+// CHECK = false is the hot path: every chunk of the tile lies inside the reduction extent, so
+// the loads are unconditional and stay in flight together until the LDS write that consumes
+// them.  CHECK = true (only the last, ragged k-tile) zero-fills whatever lies beyond K.
+template <typename T, bool KMAJOR, bool CHECK>
 __device__ __forceinline__ void stage_load(const T* __restrict__ base, long ld, int row0, int rows_max,
                                            int k0, int K, uint4 (&regs)[GemmCfg<T>::BK * 128 / GemmCfg<T>::EPC / NTHREADS]) {
   using C = GemmCfg<T>;
@@ -65,21 +75,26 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ base, long ld, 
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = t + i * NTHREADS;
-    uint4 v = make_uint4(0, 0, 0, 0);
     if (KMAJOR) {
       constexpr int CPR = C::BK / C::EPC;
       const int r = c / CPR, kc = c % CPR;
       const int k = k0 + kc * C::EPC;
       int rg = row0 + r;
       rg = rg < rows_max ? rg : rows_max - 1;
-      if (k < K) {
-        v = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k);
-        if (k + C::EPC > K) {  // chunk straddles the end of the reduction: zero the tail
-          T* e = reinterpret_cast<T*>(&v);
+      if (!CHECK) {
+        regs[i] = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k);
+      } else {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < K) {
+          v = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k);
+          if (k + C::EPC > K) {  // chunk straddles the end of the reduction: zero the tail
+            T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
-          for (int j = 0; j < C::EPC; ++j)
-            if (k + j >= K) e[j] = (T)0;
+            for (int j = 0; j < C::EPC; ++j)
+              if (k + j >= K) e[j] = (T)0;
+          }
         }
+        regs[i] = v;
       }
     } else {
       constexpr int CPR = 128 / C::EPC;
@@ -87,9 +102,14 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ base, long ld, 
       const int k = k0 + kr;
       int m = row0 + mc * C::EPC;
       m = m <= rows_max - C::EPC ? m : rows_max - C::EPC;
-      if (k < K) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + m);
+      if (!CHECK) {
+        regs[i] = *reinterpret_cast<const uint4*>(base + (long)k * ld + m);
+      } else {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < K) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + m);
+        regs[i] = v;
+      }
     }
-    regs[i] = v;
   }
 }
 
@@ -223,8 +243,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 
   uint4 ra[NCH], rb[NCH];
   const int nt = (g.K + C::BK - 1) / C::BK;
-  stage_load<T, AK>(A, g.lda, bm, g.M, 0, g.K, ra);
-  stage_load<T, BK_>(B, g.ldb, bn, g.N, 0, g.K, rb);
+  const bool ragged = (g.K % C::BK) != 0;  // only the last k-tile can reach beyond K
+  if (ragged && nt == 1) {
+    stage_load<T, AK, true>(A, g.lda, bm, g.M, 0, g.K, ra);
+    stage_load<T, BK_, true>(B, g.ldb, bn, g.N, 0, g.K, rb);
+  } else {
+    stage_load<T, AK, false>(A, g.lda, bm, g.M, 0, g.K, ra);
+    stage_load<T, BK_, false>(B, g.ldb, bn, g.N, 0, g.K, rb);
+  }
   stage_store<T, AK>(smem, ra);
   stage_store<T, BK_>(smem + OPE, rb);
   __syncthreads();
@@ -234,8 +260,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     T* la = smem + cur * 2 * OPE;
     T* lb = la + OPE;
     if (t + 1 < nt) {
-      stage_load<T, AK>(A, g.lda, bm, g.M, (t + 1) * C::BK, g.K, ra);
-      stage_load<T, BK_>(B, g.ldb, bn, g.N, (t + 1) * C::BK, g.K, rb);
+      if (ragged && t + 2 == nt) {
+        stage_load<T, AK, true>(A, g.lda, bm, g.M, (t + 1) * C::BK, g.K, ra);
+        stage_load<T, BK_, true>(B, g.ldb, bn, g.N, (t + 1) * C::BK, g.K, rb);
+      } else {
+        stage_load<T, AK, false>(A, g.lda, bm, g.M, (t + 1) * C::BK, g.K, ra);
+        stage_load<T, BK_, false>(B, g.ldb, bn, g.N, (t + 1) * C::BK, g.K, rb);
+      }
     }
     if constexpr (sizeof(T) == 2)
       mma_tile_bf16<AK, BK_>(reinterpret_cast<const bf16_t*>(la), reinterpret_cast<const bf16_t*>(lb), acc, wr, wc, lane);
@@ -343,11 +374,56 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
 
   dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == PG_BF16) {
-    if (d->c_dtype == PG_F32) return launch_layout<bf16_t, float>(d, a, grid, st);
-    return launch_layout<bf16_t, bf16_t>(d, a, grid, st);
-  } else if (d->dtype == PG_F32) {
-    return launch_layout<float, float>(d, a, grid, st);
+  ProfEntry* pe = nullptr;
+  if (g_prof.every > 0) {
+    ++g_prof.launches;
+    if (++g_prof.counter % g_prof.every == 0) {
+      ProfEntry e;
+      if (hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess) {
+        e.variant = (d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
+        e.flops = 2.0 * d->M * d->N * (double)d->K * d->batch;
+        g_prof.entries.push_back(e);
+        pe = &g_prof.entries.back();
+        hipEventRecord(pe->a, st);
+      }
+    }
   }
-  return PG_ERR_ARG;
+  int rc = PG_ERR_ARG;
+  if (d->dtype == PG_BF16) {
+    if (d->c_dtype == PG_F32) rc = launch_layout<bf16_t, float>(d, a, grid, st);
+    else rc = launch_layout<bf16_t, bf16_t>(d, a, grid, st);
+  } else if (d->dtype == PG_F32) {
+    rc = launch_layout<float, float>(d, a, grid, st);
+  }
+  if (pe) hipEventRecord(pe->b, st);
+  return rc;
+}
+
+// variant index = 8*(bf16) + 4*(fp32 output) + 2*(A k-major) + (B k-major)
+extern "C" int pg_profile_begin(int sample_every) {
+  for (auto& e : g_prof.entries) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  g_prof.entries.clear();
+  g_prof.every = sample_every > 0 ? sample_every : 0;
+  g_prof.counter = 0;
+  g_prof.launches = 0;
+  return PG_OK;
+}
+// out[16][3] = {sampled launches, sampled flops, sampled milliseconds} per variant; stops sampling.
+extern "C" int pg_profile_end(double* out, int64_t* total_launches) {
+  if (!out) return PG_ERR_ARG;
+  g_prof.every = 0;
+  for (int i = 0; i < 48; ++i) out[i] = 0.0;
+  for (auto& e : g_prof.entries) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      out[e.variant * 3 + 0] += 1.0;
+      out[e.variant * 3 + 1] += e.flops;
+      out[e.variant * 3 + 2] += ms;
+    }
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  g_prof.entries.clear();
+  if (total_launches) *total_launches = g_prof.launches;
+  return PG_OK;
 }

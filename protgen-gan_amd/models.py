@@ -23,6 +23,8 @@ class Generator(nn.Module):
         self.cls_token_id = cls_token_id
         self.sep_token_id = sep_token_id
         self.last_counts = None  # int32 [B,2] on device: (committed, masks left) of the last generate()
+        self.fill_calls = 0      # bookkeeping for throughput reports: calls and their (B, S)
+        self.fill_shapes = []
 
     def forward(self, input_ids, attention_mask=None):
         outputs = self.protbert(input_ids=input_ids, attention_mask=attention_mask)
@@ -55,6 +57,9 @@ class Generator(nn.Module):
         ops.commit_topk(ids, pred, conf, float(keep_percent), fill_all, self.mask_token_id, self.pad_token_id,
                         self.cls_token_id, self.sep_token_id, counts)
         self.last_counts = counts
+        self.fill_calls += 1
+        if len(self.fill_shapes) < 100000:
+            self.fill_shapes.append((B, S))
         if not inplace:
             input_ids.copy_(ids)
         return input_ids

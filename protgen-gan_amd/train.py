@@ -1,0 +1,174 @@
+"""The trainers' inner loops (fully_masked_train.py:195-352, 10p_train.py:132-184,296-370) as
+library functions over this package's Generator / Critic: fake-batch generation in blind
+(fully masked) and seeded (90 %-masked) mode, one critic update, one generator update, one
+GAN step (n_critic critic updates + one generator update), and the freeze schedule.
+
+Order of random draws follows the reference: Python `random` for sequence lengths
+(val_metrics.py:48-57), one CPU `torch.rand(1)` per fill iteration for the temperature
+(fully_masked_train.py:223), a device `torch.rand(ids.shape)` for the 90 % mask
+(10p_train.py:142), the device generator for the sampling noise, one CPU
+`torch.rand(B,1,1)` for the gradient-penalty interpolation (loss.py:15)."""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .loss import compute_gradient_penalty, critic_loss, generator_loss
+from .models import Critic, Generator
+
+
+@dataclass
+class GanHyper:
+    n_critic: int = 8                   # fully_masked_train.py:21
+    lambda_gp: float = 10.0             # loss.py:3 (the SLURM grids pass 5)
+    initial_masking_rate: float = 0.9   # fully_masked_train.py:83
+    iteration_fill_rate: float = 0.1    # :84
+    min_temp: float = 0.8               # :85
+    max_temp: float = 1.2               # :86
+    max_len: int = 512                  # :60, :309
+    gen_batch_blind: int = 4            # :339
+    warmup_head_lr: float = 1e-5        # :124
+
+
+def sample_sequence_length(length_pool: Sequence[int], variation: float = 0.1, rng=random) -> int:
+    """val_metrics.py:48-57 with the file's line lengths passed in as `length_pool`."""
+    base = rng.choice(length_pool)
+    var = int(base * variation)
+    return min(500, max(1, base + rng.randint(-var, var)))
+
+
+def freeze_protbert(model, freeze: bool = True):
+    """fully_masked_train.py:119-121."""
+    for p in model.protbert.parameters():
+        p.requires_grad = not freeze
+
+
+def generate_fake_batch(generator: Generator, batch_size_local: int, length_pool: Sequence[int], hp: GanHyper,
+                        device, rng=random, mask_id=4, cls_id=2, sep_id=3, pad_id=0) -> torch.Tensor:
+    """Blind mode (fully_masked_train.py:195-258): fully masked templates of sampled lengths,
+    attention mask `ids != MASK` recomputed every iteration, per-iteration temperature, then
+    pad / truncate to max_len.  The template is assembled on the host and copied once."""
+    lengths = [sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size_local)]
+    S = max(lengths)
+    ids = torch.full((batch_size_local, S), pad_id, dtype=torch.long)
+    for i, L in enumerate(lengths):
+        ids[i, :L] = mask_id
+        ids[i, 0] = cls_id
+        ids[i, L - 1] = sep_id
+    ids = ids.to(device)
+    rate = hp.initial_masking_rate
+    while rate > 0:
+        attn = (ids != mask_id).long()
+        temperature = hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp)
+        ids = generator.generate(ids, attn, temperature=temperature, keep_percent=hp.iteration_fill_rate,
+                                 current_rate=rate)
+        rate = max(0, rate - hp.iteration_fill_rate)
+        if int(generator.last_counts[:, 1].sum().item()) == 0:
+            break
+    if ids.size(1) < hp.max_len:
+        ids = F.pad(ids, (0, hp.max_len - ids.size(1)), value=pad_id)
+    elif ids.size(1) > hp.max_len:
+        ids = ids[:, :hp.max_len].contiguous()
+    return ids
+
+
+def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: GanHyper, mask_id=4, cls_id=2,
+                             sep_id=3, pad_id=0, unk_id=1) -> torch.Tensor:
+    """Seeded mode (10p_train.py:132-184): mask 90 % of the meaningful positions of real
+    sequences, attention mask `ids != PAD`, fill until no mask is left."""
+    meaningful = (input_ids != pad_id) & (input_ids != unk_id) & (input_ids != cls_id) & (input_ids != sep_id)
+    random_mask = torch.rand(input_ids.shape, device=input_ids.device) < hp.initial_masking_rate
+    ids = input_ids.clone()
+    ids[meaningful & random_mask] = mask_id
+    rate = hp.initial_masking_rate
+    while rate > 0:
+        attn = (ids != pad_id).long()
+        temperature = hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp)
+        ids = generator.generate(ids, attn, temperature=temperature, keep_percent=hp.iteration_fill_rate,
+                                 current_rate=rate)
+        rate = max(0, rate - hp.iteration_fill_rate)
+        if int(generator.last_counts[:, 1].sum().item()) == 0:
+            break
+    return ids
+
+
+def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, fake_data, hp: GanHyper,
+                  pad_id=0, grad_sync: Optional[Callable[[], None]] = None) -> torch.Tensor:
+    """fully_masked_train.py:297-326 / 10p_train.py:327-338.  `grad_sync` (data-parallel
+    gradient averaging) runs between backward and the optimizer step.  Returns c_loss
+    (device scalar; the caller decides when to synchronise for logging)."""
+    critic_optimizer.zero_grad()
+    fake = fake_data.detach()
+    fake_mask = (fake != pad_id).long()
+    gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device)
+    real_scores = critic(real_data, attention_mask=attn_mask_real)
+    fake_scores = critic(fake, attention_mask=fake_mask)
+    c_loss = critic_loss(real_scores, fake_scores, gp, hp.lambda_gp)
+    c_loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    critic_optimizer.step()
+    return c_loss.detach()
+
+
+def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0) -> torch.Tensor:
+    """fully_masked_train.py:335-352.  Token ids carry no gradient, so this back-propagates
+    into the critic only and `gen_optimizer.step()` changes nothing — kept because the
+    reference does the same work."""
+    gen_optimizer.zero_grad()
+    fake_scores = critic(fake_data, attention_mask=(fake_data != pad_id).long())
+    g_loss = generator_loss(fake_scores)
+    g_loss.backward()
+    gen_optimizer.step()
+    return g_loss.detach()
+
+
+def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
+                   real_batches: List[dict], length_pool: Sequence[int], hp: GanHyper, batch_size: int, device,
+                   rng=random, grad_sync=None):
+    """One iteration of the blind-mode training loop: n_critic critic updates (each with a
+    fresh fake batch) followed by one generator update on `gen_batch_blind` fakes."""
+    c_sum = None
+    for batch in real_batches[:hp.n_critic]:
+        fake = generate_fake_batch(generator, batch_size, length_pool, hp, device, rng=rng)
+        c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
+                          grad_sync=grad_sync)
+        c_sum = c if c_sum is None else c_sum + c
+    fake = generate_fake_batch(generator, hp.gen_batch_blind, length_pool, hp, device, rng=rng)
+    g = generator_update(critic, gen_optimizer, fake)
+    return c_sum / hp.n_critic, g
+
+
+def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
+                    real_batches: List[dict], gen_batches: List[dict], hp: GanHyper, grad_sync=None):
+    """One iteration of the seeded-mode loop (10p_train.py:296-370): needs n_critic critic
+    batches and n_critic + 1 generator batches."""
+    c_sum = None
+    for batch, gb in zip(real_batches[:hp.n_critic], gen_batches[:hp.n_critic]):
+        fake = generate_fakes_for_batch(generator, gb["input_ids"], hp)
+        c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
+                          grad_sync=grad_sync)
+        c_sum = c if c_sum is None else c_sum + c
+    fake = generate_fakes_for_batch(generator, gen_batches[hp.n_critic]["input_ids"], hp)
+    g = generator_update(critic, gen_optimizer, fake)
+    return c_sum / hp.n_critic, g
+
+
+def synthetic_real_batch(batch_size: int, length_pool: Sequence[int], max_len: int, device, rng: random.Random,
+                         gen: torch.Generator):
+    """A dataset.py-shaped batch (ids [B,max_len] int64, attention_mask [B,max_len] float) of
+    i.i.d. residues (ids 5..24) with lengths from the pool: the stand-in for the DNMT set,
+    which is not distributed with the reference."""
+    ids = torch.zeros(batch_size, max_len, dtype=torch.long)
+    mask = torch.zeros(batch_size, max_len, dtype=torch.float32)
+    for b in range(batch_size):
+        L = min(rng.choice(length_pool), max_len - 2)
+        ids[b, 0] = 2
+        ids[b, 1:L + 1] = torch.randint(5, 25, (L,), generator=gen)
+        ids[b, L + 1] = 3
+        mask[b, :L + 2] = 1.0
+    return {"input_ids": ids.to(device), "attention_mask": mask.to(device)}
