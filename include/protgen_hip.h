@@ -101,6 +101,7 @@ int pg_gemm(const pg_gemm_desc* d, void* stream);
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
+int pg_tune(int key, int value); /* key 0: 1 = direct-to-LDS bf16 GEMM when eligible (default), 0 = register-staged */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 
@@ -144,6 +145,10 @@ int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float*
  * (modeling_bert.py:125-130) with the additive mask (1-m)*finfo(float32).min
  * (modeling_utils.py:1012-1024).  Outputs of activation dtype have row stride ldS and
  * zeros in columns >= S.                                                                */
+/* Fused (flash-style) forward for passes that keep nothing for a backward: ctx = softmax(Q K^T/8
+ * + keymask) V straight from the packed [T][3H] QKV buffer, bf16 only, S <= 2048. */
+int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
+                     int64_t ld_qkv, int64_t ld_ctx, void* stream);
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pg_head_total": (i64, [i32]),
     "pg_head_offset": (i64, [i32, i32, i32]),
     "pg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "pg_tune": (i32, [i32, i32]),
     "pg_profile_begin": (i32, [i32]),
     "pg_profile_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pg_embed_ln": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "pg_layernorm_bwd2": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp]),
     "pg_gelu_bwd2": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "pg_colsum_acc": (i32, [i32, vp, i64, i32, i32, vp, vp]),
+    "pg_attention_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
     "pg_score_ld": (i32, [i32]),
     "pg_softmax_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "pg_softmax_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp]),

@@ -1,0 +1,267 @@
+// Fused attention forward (bf16, head_dim 64) for the inference passes of the fill loop:
+//   ctx = softmax(Q K^T / 8 + keymask) V      (modeling_bert.py:111-136, eager_attention_forward)
+// without materialising the [S,S] score matrix.  One workgroup = 4 waves = 128 query rows of
+// one (batch, head); each wave owns 32 query rows (two 16-row groups) and walks the keys in
+// 64-key tiles.  K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4) into a two-buffer
+// ring, XOR-swizzled on the source address (chunk c of row r sits at position c ^ (r & 7)).
+//
+// Both products are issued "transposed" so the query index sits on the MFMA lane:
+//   S^T = K Q^T : lane (q = lane & 15, g = lane >> 4) holds keys 16*blk + 4g + reg of query q
+//   O^T = V^T P^T: the exponentiated scores of two 16-key blocks are, as they stand in the
+//                  accumulator registers, the B operand of a 32-deep MFMA step whose k-slots
+//                  are keys {4g + j, 16 + 4g + j}; the A operand (V^T) for exactly those slots
+//                  is what two transposing LDS reads (ds_read_b64_tr_b16) deliver.
+// So the online-softmax statistics are per lane (plus two cross-lane shuffles), nothing goes
+// through LDS between the two products, and each lane ends with 4 consecutive head-dim
+// values of one query row: 8-byte output stores.
+#include <float.h>
+#include <math.h>
+#include "pg_common.h"
+#include "protgen_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int QB = 128;      // query rows per workgroup
+constexpr int KT = 64;       // keys per tile
+constexpr int TILE = KT * 64;  // bf16 elements of one K (or V) tile: 8 KiB
+constexpr int MAX_S = 2048;    // additive key mask of one batch row lives in LDS
+
+template <int IMM>
+__device__ __forceinline__ u32x4 rd128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+template <int IMM>
+__device__ __forceinline__ u32x2 rdtr(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+
+// One 64-row x 128-byte tile: 8 wave-instructions of 1 KiB, two per wave.
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long ld, int row0, int rows_max, bf16_t* lds_tile,
+                                           int wid, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = wid * 2 + j;
+    const int r = 8 * i + (lane >> 3);
+    const int c = (lane & 7) ^ (lane >> 3);
+    int rg = row0 + r;
+    rg = rg < rows_max ? rg : rows_max - 1;
+    __builtin_amdgcn_global_load_lds(base + (long)rg * ld + c * 8, lds_tile + i * 512, 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
+                                                           bf16_t* __restrict__ ctx, int S, int heads, long ld_qkv, long ld_ctx) {
+  // [buffer][K|V] tiles, then the additive key mask (fp32) of this batch row.  One array only:
+  // a second __shared__ object would make the compiler drain the LDS-DMA before LDS reads.
+  __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
+  const int bh = blockIdx.y;
+  const int b = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* Q = qkv + (long)b * S * ld_qkv + h * 64;
+  const bf16_t* K = Q + H;
+  const bf16_t* V = Q + 2 * H;
+  const float* mrow = mask ? mask + (long)b * S : nullptr;
+  const int q0 = blockIdx.x * QB + wid * 32;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32kk + 8g .. +8]
+  bf16x8_t qf[2][2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    int q = q0 + qg * 16 + r;
+    q = q < S ? q : S - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 v = *reinterpret_cast<const uint4*>(Q + (long)q * ld_qkv + kk * 32 + 8 * g);
+      qf[qg][kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  {
+    float* ml = reinterpret_cast<float*>(smem + 4 * TILE);
+    const int s_pad = ((S + KT - 1) / KT) * KT;
+    for (int k = threadIdx.x; k < s_pad; k += 256) {
+      float a = 0.f;
+      if (k >= S) a = -INFINITY;                               // beyond the sequence: weight exactly 0
+      else if (mrow) a = (1.0f - mrow[k]) * -FLT_MAX;          // HF additive mask, finfo(float32).min
+      ml[k] = a;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  f32x4 o[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    m_run[qg] = -INFINITY;
+    l_run[qg] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // per-lane LDS byte offsets inside a tile
+  unsigned koff[2];  // K fragment: row 16*blk + r (blk adds 2048), chunk 4kk + g
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  unsigned voff[2][4];  // V^T fragment: key row 4g + q' (+16), d-block dblk; k-step s2 adds 4096
+  {
+    const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int k = 4 * g + qq + 16 * hi;
+        const int c = 2 * d + (pp >> 1);
+        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+      }
+  }
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const unsigned mask_addr = smem_addr + 4 * TILE * 2;
+
+  const int nt = (S + KT - 1) / KT;
+  stage_tile(K, ld_qkv, 0, S, smem, wid, lane);
+  stage_tile(V, ld_qkv, 0, S, smem + TILE, wid, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+      bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      stage_tile(K, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
+      stage_tile(V, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+    }
+    const unsigned ka = smem_addr + (t & 1) * 4 * TILE;
+    const unsigned va = ka + 2 * TILE;
+    // ---- additive mask of this lane's 16 keys of the tile (4 consecutive keys per block)
+    u32x4 mraw[4];
+    {
+      const unsigned ma = mask_addr + (unsigned)((t * KT + 4 * g) * 4);
+      mraw[0] = rd128<0>(ma);
+      mraw[1] = rd128<64>(ma);
+      mraw[2] = rd128<128>(ma);
+      mraw[3] = rd128<192>(ma);
+    }
+    // ---- K fragments, then S^T = K Q^T
+    u32x4 kf[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[0][kk] = rd128<0>(ka + koff[kk]);
+      kf[1][kk] = rd128<2048>(ka + koff[kk]);
+      kf[2][kk] = rd128<4096>(ka + koff[kk]);
+      kf[3][kk] = rd128<6144>(ka + koff[kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 s[2][4];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][0]), qf[qg][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][1]), qf[qg][1], a, 0, 0, 0);
+        s[qg][blk] = a;
+      }
+    // ---- V^T fragments in flight under the softmax arithmetic
+    u32x2 vlo[2][4], vhi[2][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      vlo[0][d] = rdtr<0>(va + voff[0][d]);
+      vhi[0][d] = rdtr<0>(va + voff[1][d]);
+      vlo[1][d] = rdtr<4096>(va + voff[0][d]);
+      vhi[1][d] = rdtr<4096>(va + voff[1][d]);
+    }
+    float madd[4][4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) madd[blk][e] = __uint_as_float(mraw[blk][e]);
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = s[qg][blk][e] * 0.125f + madd[blk][e];
+          s[qg][blk][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qg], mx);
+      const float alpha = __expf(m_run[qg] - m_new);
+      float sum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __expf(s[qg][blk][e] - m_new);
+          s[qg][blk][e] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      l_run[qg] = l_run[qg] * alpha + sum;
+      m_run[qg] = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[qg][d] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p8[e] = (__bf16)s[qg][2 * s2][e];
+          p8[4 + e] = (__bf16)s[qg][2 * s2 + 1][e];
+        }
+        pf[qg][s2] = p8;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 vv = (u32x4){vlo[s2][d][0], vlo[s2][d][1], vhi[s2][d][0], vhi[s2][d][1]};
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+  // ---- normalise and store: lane holds ctx[q][h*64 + 16d + 4g .. +4]
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    if (q >= S) continue;
+    const float inv = 1.0f / l_run[qg];
+    bf16_t* dst = ctx + ((long)b * S + q) * ld_ctx + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float v[4] = {o[qg][d][0] * inv, o[qg][d][1] * inv, o[qg][d][2] * inv, o[qg][d][3] * inv};
+      VecIO<bf16_t, 4>::store(dst + d * 16, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
+                                int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!qkv || !ctx || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return PG_ERR_ALIGN;
+  dim3 grid((S + QB - 1) / QB, B * heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, S,
+                     heads, (long)ld_qkv, (long)ld_ctx);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}

@@ -239,7 +239,7 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
   if (!make_dims(cfg, dtype, B, S, d) || !p || !p->master || (!ids && !x_in) || !workspace) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   if (!stash && !hidden_out) return PG_ERR_ARG;
-  if (d.ldS > 1024) return PG_ERR_UNSUPPORTED;
+  if (d.ldS > 1024 && !(!stash && dtype == PG_BF16 && S <= 2048)) return PG_ERR_UNSUPPORTED;
   Workspace w = ws_layout(d, (char*)workspace);
   if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -268,13 +268,18 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
     // QKV projection (BertSelfAttention.query/key/value as one [3H,H] matrix)
     CK(g.run(s.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, s.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f,
              pv.m(pv.lo(l, PG_L_BQ))));
-    // scores = Q K^T / 8
-    CK(g.bat(d, s.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-             0.125f, 0.f));
-    CK(pg_softmax_fwd(dtype, w.sc0, mask, s.ss, B, d.nh, S, st));
-    // ctx = P V
-    CK(g.bat(d, s.ss, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, s.ctx, dtype, H, false, S, 64, S, 1.f,
-             0.f));
+    if (!stash && dtype == PG_BF16 && S <= 2048) {
+      // nothing is kept for a backward: fused attention, no score matrix in HBM
+      CK(pg_attention_fwd(dtype, s.qkv, mask, s.ctx, B, S, d.nh, 3 * H, H, st));
+    } else {
+      // scores = Q K^T / 8
+      CK(g.bat(d, s.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+               0.125f, 0.f));
+      CK(pg_softmax_fwd(dtype, w.sc0, mask, s.ss, B, d.nh, S, st));
+      // ctx = P V
+      CK(g.bat(d, s.ss, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, s.ctx, dtype, H, false, S, 64, S,
+               1.f, 0.f));
+    }
     // a = ctx Wo^T + bo + x ; h = LN1(a)
     CK(g.run(s.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, s.a, dtype, H, T, H, H, 1.f, 0.f, pv.m(pv.lo(l, PG_L_BO)),
              s.x, H));

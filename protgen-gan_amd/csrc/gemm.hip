@@ -218,6 +218,148 @@ template <typename TC> __device__ __forceinline__ void store4(TC* p, const float
   }
 }
 
+// ---- epilogue: lane owns C[m][n..n+3], m = ... + (lane&15), n = ... + 4*(lane>>4)
+// Interior tiles with vector-aligned operands take a branch-free path: the bias is fetched
+// once per column group as a float4, and the residual / auxiliary / accumulate loads of one
+// output row group are all issued before the first is consumed.
+template <typename T> __device__ __forceinline__ float gelu_epi(float x);
+template <> __device__ __forceinline__ float gelu_epi<float>(float x) { return gelu_f(x); }
+template <> __device__ __forceinline__ float gelu_epi<bf16_t>(float x) { return gelu_fast(x); }
+template <typename T> __device__ __forceinline__ float gelu_d1_epi(float x);
+template <> __device__ __forceinline__ float gelu_d1_epi<float>(float x) { return gelu_d1(x); }
+template <> __device__ __forceinline__ float gelu_d1_epi<bf16_t>(float x) { return gelu_d1_fast(x); }
+
+template <typename T, typename TC>
+__device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[4][4], const GemmArgs& g, TC* Cp, int bm, int bn, int wr,
+                                                       int wc, int lane) {
+  const int n0 = bn + wc * 64 + 4 * (lane >> 4);
+  const int m0 = bm + wr * 64 + (lane & 15);
+  float bv[4][4];
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) VecIO<float, 4>::load(g.bias + n0 + j * 16, bv[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
+  }
+  const T* aux = reinterpret_cast<const T*>(g.aux);
+  const T* res = reinterpret_cast<const T*>(g.residual);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + i * 16;
+#pragma unroll
+    for (int jh = 0; jh < 4; jh += 2) {  // two column groups at a time keeps the live set small
+      float v[2][4], u[2][4], r[2][4], c0[2][4];
+      if (g.act == PG_ACT_MUL_DGELU) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) VecIO<T, 4>::load(aux + m * g.ldaux + n0 + (jh + j) * 16, u[j]);
+      }
+      if (res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) VecIO<T, 4>::load(res + m * g.ldr + n0 + (jh + j) * 16, r[j]);
+      }
+      if (g.beta != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) VecIO<TC, 4>::load(Cp + m * g.ldc + n0 + (jh + j) * 16, c0[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = acc[i][jh + j][e] * g.alpha + bv[jh + j][e];
+      if (g.act == PG_ACT_GELU) {
+        if (g.aux) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            VecIO<T, 4>::store(reinterpret_cast<T*>(g.aux) + m * g.ldaux + n0 + (jh + j) * 16, v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = gelu_epi<T>(v[j][e]);
+      } else if (g.act == PG_ACT_MUL_DGELU) {
+        if (g.aux2) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            VecIO<T, 4>::store(reinterpret_cast<T*>(g.aux2) + m * g.ldaux + n0 + (jh + j) * 16, v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] *= gelu_d1_epi<T>(u[j][e]);
+      }
+      if (res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] += r[j][e];
+      }
+      if (g.beta != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] += g.beta * c0[j][e];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) VecIO<TC, 4>::store(Cp + m * g.ldc + n0 + (jh + j) * 16, v[j]);
+    }
+  }
+}
+
+template <typename T, typename TC>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], const GemmArgs& g, TC* Cp, int bm, int bn, int wr, int wc,
+                                              int lane) {
+  if (g.vec_ok && bm + BM <= g.M && bn + BN <= g.N) {
+    gemm_epilogue_interior<T, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
+    return;
+  }
+  const bool vec = g.vec_ok != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm + wr * 64 + i * 16 + (lane & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = bn + wc * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= g.N) continue;
+      const int nvalid = g.N - n < 4 ? g.N - n : 4;
+      const bool v4 = vec && nvalid == 4;
+      float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+      if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) v[e] += g.bias[n + e];
+      }
+      if (g.act == PG_ACT_GELU) {
+        if (g.aux) store4<T>(reinterpret_cast<T*>(g.aux) + (long)m * g.ldaux + n, v, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      } else if (g.act == PG_ACT_MUL_DGELU) {
+        float u[4];
+        load4<T>(reinterpret_cast<const T*>(g.aux) + (long)m * g.ldaux + n, u, v4, nvalid);
+        if (g.aux2) store4<T>(reinterpret_cast<T*>(g.aux2) + (long)m * g.ldaux + n, v, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_d1(u[e]);
+      }
+      if (g.residual) {
+        float r[4];
+        load4<T>(reinterpret_cast<const T*>(g.residual) + (long)m * g.ldr + n, r, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      TC* cp = Cp + (long)m * g.ldc + n;
+      if (g.beta != 0.f) {
+        float c0[4];
+        load4<TC>(cp, c0, v4, nvalid);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += g.beta * c0[e];
+      }
+      store4<TC>(cp, v, v4, nvalid);
+    }
+  }
+}
+
 template <typename T, typename TC, bool AK, bool BK_>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
   using C = GemmCfg<T>;
@@ -280,51 +422,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns C[m][n..n+3], m = ... + (lane&15), n = ... + 4*(lane>>4)
-  const bool vec = g.vec_ok != 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = bm + wr * 64 + i * 16 + (lane & 15);
-    if (m >= g.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = bn + wc * 64 + j * 16 + 4 * (lane >> 4);
-      if (n >= g.N) continue;
-      const int nvalid = g.N - n < 4 ? g.N - n : 4;
-      const bool v4 = vec && nvalid == 4;
-      float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
-      if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) v[e] += g.bias[n + e];
-      }
-      if (g.act == PG_ACT_GELU) {
-        if (g.aux) store4<T>(reinterpret_cast<T*>(g.aux) + (long)m * g.ldaux + n, v, v4, nvalid);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      } else if (g.act == PG_ACT_MUL_DGELU) {
-        float u[4];
-        load4<T>(reinterpret_cast<const T*>(g.aux) + (long)m * g.ldaux + n, u, v4, nvalid);
-        if (g.aux2) store4<T>(reinterpret_cast<T*>(g.aux2) + (long)m * g.ldaux + n, v, v4, nvalid);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_d1(u[e]);
-      }
-      if (g.residual) {
-        float r[4];
-        load4<T>(reinterpret_cast<const T*>(g.residual) + (long)m * g.ldr + n, r, v4, nvalid);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-      }
-      TC* cp = Cp + (long)m * g.ldc + n;
-      if (g.beta != 0.f) {
-        float c0[4];
-        load4<TC>(cp, c0, v4, nvalid);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += g.beta * c0[e];
-      }
-      store4<TC>(cp, v, v4, nvalid);
-    }
-  }
+  gemm_epilogue<T, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
 }
 
 template <typename T, typename TC>
@@ -336,7 +434,229 @@ int launch_layout(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
+// ======================================================================================
+// bf16 fast path: operand tiles go global -> LDS directly (global_load_lds_dwordx4, no
+// staging registers, no ds_write), two LDS buffers, the loads of k-tile t+1 in flight under
+// the MFMAs of tile t.  A wave instruction writes 1 KiB of LDS linearly (lane * 16 B), so
+// the bank-conflict swizzle is applied to the per-lane SOURCE address and undone by the
+// same XOR on the fragment read:
+//   k-major tile [128 rows][64 bf16] (128-B rows):  chunk c of row r sits at position c ^ (r & 7)
+//   m-major tile [64 k][128 bf16]   (256-B rows):  chunk c of row k sits at position c ^ swz(k),
+//                                                  swz(k) = ((k & 3) << 2) | ((k >> 2) & 3)
+// Requires K % 64 == 0 (whole tiles only: nothing can be masked on the way into LDS).
+constexpr int GBK = 64;
+constexpr int GT_ELEMS = 128 * GBK;  // 8192 bf16 = 16 KiB per operand tile
+
+__device__ __forceinline__ int swz_m(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void glds_stage(const bf16_t* __restrict__ base, long ld, int row0, int rows_max, int k0,
+                                           bf16_t* lds_tile, int wid, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wid * 4 + j;  // wave instruction index 0..15, 1 KiB of the tile each
+    const bf16_t* src;
+    if (KMAJOR) {
+      const int r = 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ (lane >> 3);  // (r & 7) == lane >> 3
+      int rg = row0 + r;
+      rg = rg < rows_max ? rg : rows_max - 1;
+      src = base + (long)rg * ld + k0 + c * 8;
+    } else {
+      const int k = 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ swz_m(k);
+      int m = row0 + c * 8;
+      m = m <= rows_max - 8 ? m : rows_max - 8;
+      src = base + (long)(k0 + k) * ld + m;
+    }
+    __builtin_amdgcn_global_load_lds(src, lds_tile + i * 512, 16, 0, 0);
+  }
+}
+
+// Fragment reads are inline asm: a compiler-visible ds_read of the staging array makes hipcc
+// wait vmcnt(0) first (it cannot tell which in-flight LDS-DMA it may alias), which would
+// drain the prefetch ring before every k-tile.  The waits are therefore counted by hand:
+// reads return in issue order, lgkmcnt(n) = "all but the n youngest have returned".
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int IMM>
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+template <int IMM>
+__device__ __forceinline__ u32x2 lds_read_tr_b64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+
+// Per-lane byte offsets (inside one 16 KiB operand tile) of the fragments a lane reads; they do
+// not depend on the k-tile, so they are computed once per kernel.
+//   k-major: off[kk]; tile row block i adds i*2048 (immediate)
+//   m-major: off[hi*4 + i]; k-step kk adds kk*8192 (immediate)
+template <bool KMAJOR> struct FragOff { unsigned off[KMAJOR ? 2 : 8]; };
+
+template <bool KMAJOR>
+__device__ __forceinline__ FragOff<KMAJOR> frag_offsets(int wsel, int lane) {
+  FragOff<KMAJOR> f;
+  const int r = lane & 15, g = lane >> 4;
+  if constexpr (KMAJOR) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) f.off[kk] = (unsigned)((wsel * 64 + r) * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  } else {
+    const int q = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 8 * g + q + 4 * hi;
+        const int ch = wsel * 8 + 2 * i + (pp >> 1);
+        f.off[hi * 4 + i] = (unsigned)(k * 256 + ((ch ^ swz_m(k)) << 4) + 8 * (pp & 1));
+      }
+  }
+  return f;
+}
+
+template <bool KMAJOR, int KK>
+__device__ __forceinline__ void read_frags(unsigned tile_addr, const FragOff<KMAJOR>& f, u32x4 (&out)[4]) {
+  if constexpr (KMAJOR) {
+    const unsigned a = tile_addr + f.off[KK];
+    out[0] = lds_read_b128<0>(a);
+    out[1] = lds_read_b128<2048>(a);
+    out[2] = lds_read_b128<4096>(a);
+    out[3] = lds_read_b128<6144>(a);
+  } else {
+#define PG_TR_PAIR(I)                                                         \
+    {                                                                         \
+      u32x2 lo = lds_read_tr_b64<KK * 8192>(tile_addr + f.off[I]);           \
+      u32x2 hi = lds_read_tr_b64<KK * 8192>(tile_addr + f.off[4 + I]);       \
+      out[I] = (u32x4){lo[0], lo[1], hi[0], hi[1]};                          \
+    }
+    PG_TR_PAIR(0) PG_TR_PAIR(1) PG_TR_PAIR(2) PG_TR_PAIR(3)
+#undef PG_TR_PAIR
+  }
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void glds_compute(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa, const FragOff<BK_>& fb,
+                                             f32x4 (&acc)[4][4]) {
+  u32x4 a0[4], b0[4], a1[4], b1[4];
+  read_frags<AK, 0>(a_addr, fa, a0);
+  read_frags<BK_, 0>(b_addr, fb, b0);
+  read_frags<AK, 1>(a_addr, fa, a1);
+  read_frags<BK_, 1>(b_addr, fb, b1);
+  constexpr int second = (AK ? 4 : 8) + (BK_ ? 4 : 8);  // reads issued for k-step 1
+  if constexpr (second <= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (second <= 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b0[j]), __builtin_bit_cast(bf16x8_t, a0[i]),
+                                                          acc[i][j], 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b1[j]), __builtin_bit_cast(bf16x8_t, a1[i]),
+                                                          acc[i][j], 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// NST = 2: two LDS buffers, one k-tile in flight under the MFMAs, two workgroups per CU.
+// NST = 4: four-buffer ring, up to three k-tiles in flight behind a counted vmcnt and a raw
+//          s_barrier (one barrier per k-tile), one workgroup per CU: for grids of about one
+//          workgroup per CU, where nothing else hides the HBM/L2 latency.
+template <typename TC, bool AK, bool BK_, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(GemmArgs g) {
+  __shared__ __align__(16) bf16_t smem[NST * 2 * GT_ELEMS];  // [buffer][A|B][16 KiB]
+  const int z = blockIdx.z;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / GBK;
+  const FragOff<AK> fa = frag_offsets<AK>(wr, lane);
+  const FragOff<BK_> fb = frag_offsets<BK_>(wc, lane);
+  const unsigned smem_addr = lds_addr(smem);
+  if constexpr (NST == 2) {
+    glds_stage<AK>(A, g.lda, bm, g.M, 0, smem, wid, lane);
+    glds_stage<BK_>(B, g.ldb, bn, g.N, 0, smem + GT_ELEMS, wid, lane);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const unsigned la = smem_addr + (t & 1) * 4 * GT_ELEMS;
+      if (t + 1 < nt) {
+        bf16_t* na = smem + ((t + 1) & 1) * 2 * GT_ELEMS;
+        glds_stage<AK>(A, g.lda, bm, g.M, (t + 1) * GBK, na, wid, lane);
+        glds_stage<BK_>(B, g.ldb, bn, g.N, (t + 1) * GBK, na + GT_ELEMS, wid, lane);
+      }
+      glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
+      __syncthreads();
+    }
+  } else {
+    // every wave issues 8 LDS-DMA loads per k-tile; vmcnt(8 * tiles allowed to stay in flight)
+    const int pre = nt < NST - 1 ? nt : NST - 1;
+    for (int t = 0; t < pre; ++t) {
+      bf16_t* na = smem + t * 2 * GT_ELEMS;
+      glds_stage<AK>(A, g.lda, bm, g.M, t * GBK, na, wid, lane);
+      glds_stage<BK_>(B, g.ldb, bn, g.N, t * GBK, na + GT_ELEMS, wid, lane);
+    }
+    for (int t = 0; t < nt; ++t) {
+      const int ahead = nt - 1 - t;  // tiles issued after tile t that may remain in flight
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1)%NST is free again
+      if (t + NST - 1 < nt) {
+        bf16_t* na = smem + ((t + NST - 1) % NST) * 2 * GT_ELEMS;
+        glds_stage<AK>(A, g.lda, bm, g.M, (t + NST - 1) * GBK, na, wid, lane);
+        glds_stage<BK_>(B, g.ldb, bn, g.N, (t + NST - 1) * GBK, na + GT_ELEMS, wid, lane);
+      }
+      const unsigned la = smem_addr + (t % NST) * 4 * GT_ELEMS;
+      glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
+    }
+  }
+  gemm_epilogue<bf16_t, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
+}
+
+template <typename TC, int NST>
+int launch_glds(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, true, NST>), grid, dim3(NTHREADS), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, false, NST>), grid, dim3(NTHREADS), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_kernel<TC, false, true, NST>), grid, dim3(NTHREADS), 0, st, a);
+  else hipLaunchKernelGGL((gemm_glds_kernel<TC, false, false, NST>), grid, dim3(NTHREADS), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
+
 }  // namespace
+
+extern "C" int pg_tune(int key, int value) {
+  if (key == 0) { g_gemm_path = value; return PG_OK; }
+  return PG_ERR_ARG;
+}
 
 extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return PG_ERR_ARG;
@@ -369,6 +689,7 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   bool vec = (d->ldc % 4 == 0) && (d->sCo % 4 == 0) && (d->sCi % 4 == 0) && (((uintptr_t)d->C) % (4 * csz) == 0);
   if (d->residual) vec = vec && (d->ldr % 4 == 0) && (((uintptr_t)d->residual) % (4 * tsz) == 0);
   if (d->aux) vec = vec && (d->ldaux % 4 == 0) && (((uintptr_t)d->aux) % (4 * tsz) == 0);
+  if (d->bias) vec = vec && (((uintptr_t)d->bias) % 16 == 0);
   if (a.aux2) vec = vec && (((uintptr_t)a.aux2) % (4 * tsz) == 0);
   a.vec_ok = vec ? 1 : 0;
 
@@ -389,7 +710,19 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
     }
   }
   int rc = PG_ERR_ARG;
-  if (d->dtype == PG_BF16) {
+  const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
+                    (d->b_kmajor || d->N >= 8);
+  if (fast) {
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
+    if (deep) {
+      if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);
+      else rc = launch_glds<bf16_t, 4>(d, a, grid, st);
+    } else {
+      if (d->c_dtype == PG_F32) rc = launch_glds<float, 2>(d, a, grid, st);
+      else rc = launch_glds<bf16_t, 2>(d, a, grid, st);
+    }
+  } else if (d->dtype == PG_BF16) {
     if (d->c_dtype == PG_F32) rc = launch_layout<bf16_t, float>(d, a, grid, st);
     else rc = launch_layout<bf16_t, bf16_t>(d, a, grid, st);
   } else if (d->dtype == PG_F32) {

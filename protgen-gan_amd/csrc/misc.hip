@@ -176,7 +176,7 @@ __device__ __forceinline__ void block_matvec_t(const float* __restrict__ W, cons
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ hidden, long row_stride,
+__global__ __launch_bounds__(1024) void head_fwd_kernel(const T* __restrict__ hidden, long row_stride,
                                                         const float* __restrict__ head, int H, float* __restrict__ scores,
                                                         float* __restrict__ stash) {
   const HeadDims hd = head_dims(H);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ hid
 // overwrites the activation slots' roles: t1,t2,t3 are written where a1..a3 were read from a
 // second stash (tstash), keeping the primal stash intact.
 template <typename T>
-__global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restrict__ head, float* __restrict__ stash,
+__global__ __launch_bounds__(1024) void head_bwd_vec_kernel(const float* __restrict__ head, float* __restrict__ stash,
                                                             const float* __restrict__ w, int H, T* __restrict__ dhidden,
                                                             long row_stride) {
   const HeadDims hd = head_dims(H);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void head_bwd_vec_kernel(const float* __restri
 // Tangent through the gated head: t1 = gate1*(W0 xdot), t2 = gate2*(W2 t1), t3 = gate3*(W4 t2),
 // sdot = W6 t3.  tstash layout: [xdot d0][t1 d1][t2 d2][t3 d3].
 template <typename T>
-__global__ __launch_bounds__(256) void head_jvp_kernel(const float* __restrict__ head, const float* __restrict__ stash,
+__global__ __launch_bounds__(1024) void head_jvp_kernel(const float* __restrict__ head, const float* __restrict__ stash,
                                                         const T* __restrict__ hdot, long row_stride, int H,
                                                         float* __restrict__ tstash, float* __restrict__ sdot) {
   const HeadDims hd = head_dims(H);
@@ -263,11 +263,15 @@ __global__ __launch_bounds__(256) void head_jvp_kernel(const float* __restrict__
   __syncthreads();
   float s = 0.f;
   for (int i = threadIdx.x; i < hd.d[3]; i += blockDim.x) s += head[hd.w[3] + i] * t3[i];
-  __shared__ float red[4];
+  __shared__ float red[16];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0 && sdot) sdot[b] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0 && sdot) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    sdot[b] = t;
+  }
 }
 
 // Weight gradients: gW_l[o][i] += scale * sum_b vec_l[b][o] * act_l[b][i]; gb_l[o] += scale*sum_b vec_l[b][o].
@@ -487,10 +491,10 @@ extern "C" int pg_head_forward(int dtype, const void* hidden, int64_t row_stride
   if (!hidden || !head || !scores || !stash || B <= 0 || H < 16 || (H % 16)) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PG_F32)
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)hidden, (long)row_stride, head, H,
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(1024), 0, st, (const float*)hidden, (long)row_stride, head, H,
                        scores, stash);
   else
-    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)hidden, (long)row_stride, head,
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(B), dim3(1024), 0, st, (const bf16_t*)hidden, (long)row_stride, head,
                        H, scores, stash);
   return check_launch();
 }
@@ -500,10 +504,10 @@ extern "C" int pg_head_backward(int dtype, const float* head, float* stash, cons
   if (!head || !stash || B <= 0 || H < 16 || (H % 16)) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PG_F32)
-    hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3(B), dim3(256), 0, st, head, stash, w, H, (float*)dhidden,
+    hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3(B), dim3(1024), 0, st, head, stash, w, H, (float*)dhidden,
                        (long)row_stride);
   else
-    hipLaunchKernelGGL(head_bwd_vec_kernel<bf16_t>, dim3(B), dim3(256), 0, st, head, stash, w, H, (bf16_t*)dhidden,
+    hipLaunchKernelGGL(head_bwd_vec_kernel<bf16_t>, dim3(B), dim3(1024), 0, st, head, stash, w, H, (bf16_t*)dhidden,
                        (long)row_stride);
   if (hipGetLastError() != hipSuccess) return PG_ERR_LAUNCH;
   if (ghead) {
@@ -519,13 +523,13 @@ extern "C" int pg_head_jvp_grad(int dtype, const float* head, float* stash, cons
   if (!head || !stash || !hdot || !tstash || B <= 0 || H < 16 || (H % 16)) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   // unit-weight backward vectors (the adjoints of the tangents) into the primal stash's v slots
-  hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3(B), dim3(256), 0, st, head, stash, (const float*)nullptr, H,
+  hipLaunchKernelGGL(head_bwd_vec_kernel<float>, dim3(B), dim3(1024), 0, st, head, stash, (const float*)nullptr, H,
                      (float*)nullptr, 0L);
   if (dtype == PG_F32)
-    hipLaunchKernelGGL(head_jvp_kernel<float>, dim3(B), dim3(256), 0, st, head, stash, (const float*)hdot,
+    hipLaunchKernelGGL(head_jvp_kernel<float>, dim3(B), dim3(1024), 0, st, head, stash, (const float*)hdot,
                        (long)row_stride, H, tstash, sdot_out);
   else
-    hipLaunchKernelGGL(head_jvp_kernel<bf16_t>, dim3(B), dim3(256), 0, st, head, stash, (const bf16_t*)hdot,
+    hipLaunchKernelGGL(head_jvp_kernel<bf16_t>, dim3(B), dim3(1024), 0, st, head, stash, (const bf16_t*)hdot,
                        (long)row_stride, H, tstash, sdot_out);
   if (hipGetLastError() != hipSuccess) return PG_ERR_LAUNCH;
   if (ghead) {

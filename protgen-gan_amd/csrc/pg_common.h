@@ -42,6 +42,21 @@ __device__ __forceinline__ float gelu_d2(float x) {
   return pdf * (2.0f - x * x);
 }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): used where the result is rounded
+// to bf16 anyway; the fp32 path keeps the library erff.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - p * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_d1_fast(float x) {
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_jvp_kernel(const T* __restrict__ xin, 
 // ------------------------------------------------------------------ LN backward (first and second order)
 // Each wave walks rows wave_id, wave_id + n_waves, ... and keeps its dgamma/dbeta partial
 // sums in registers; partials go to `partial[wave][2][H]` and are reduced by
-// ln_param_reduce_kernel (deterministic, no atomics).
+// ln_param_reduce_kernel.
 template <typename T, int VW, int NCH, bool SECOND>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, const T* __restrict__ xdot,
                                                       const T* __restrict__ gy, const T* __restrict__ ybar,
@@ -215,14 +215,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, 
   }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, int n_waves, int H, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // column in [0, 2H)
-  if (c >= 2 * H) return;
+// grid (ceil(2H/64), row_chunks): thread (c = tid&63, rg = tid>>6) sums partial rows rg, rg+4, ...
+// of its chunk for column c; the four row groups combine through LDS; one atomic per column.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int n_waves, int H,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int rows_per_chunk) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;  // column in [0, 2H)
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(n_waves, r0 + rows_per_chunk);
   float s = 0.f;
-  for (int w = 0; w < n_waves; ++w) s += partial[(long)w * 2 * H + c];
-  if (c < H) { if (dgamma) dgamma[c] += s; }
-  else { if (dbeta) dbeta[c - H] += s; }
+  if (c < 2 * H)
+    for (int w = r0 + rg; w < r1; w += 4) s += partial[(long)w * 2 * H + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * H) {
+    const float t = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+    if (c < H) { if (dgamma) atomicAdd(dgamma + c, t); }
+    else { if (dbeta) atomicAdd(dbeta + c - H, t); }
+  }
 }
 
 // ------------------------------------------------------------------ GELU second-order reverse
@@ -501,8 +513,11 @@ int ln_bwd_launch(int dtype, const void* x, const void* xdot, const void* gy, co
   }
   if (hipGetLastError() != hipSuccess) return PG_ERR_LAUNCH;
   if (want_params) {
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, st, partial, n_waves, H, dgamma,
-                       dbeta);
+    int chunks = (n_waves + 63) / 64;
+    if (chunks > 16) chunks = 16;
+    const int rpc = (n_waves + chunks - 1) / chunks;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * H + 63) / 64, chunks), dim3(256), 0, st, partial, n_waves, H,
+                       dgamma, dbeta, rpc);
   }
   return check_launch();
 }

@@ -186,3 +186,12 @@ def adamw(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
 
 def cast_bf16(src, dst):
     check(lib.pg_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream()), "pg_cast_bf16")
+
+
+def attention_fwd(qkv, mask, B, S, heads):
+    """qkv: [B*S, 3*heads*64] bf16 packed (q | k | v); returns ctx [B*S, heads*64]."""
+    H = heads * 64
+    ctx = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
+    check(lib.pg_attention_fwd(dt_code(qkv.dtype), qkv.data_ptr(), ptr(mask), ctx.data_ptr(), B, S, heads, qkv.stride(0),
+                               ctx.stride(0), stream()), "pg_attention_fwd")
+    return ctx

@@ -47,13 +47,16 @@ def rnd(*shape, dtype=torch.float32, scale=1.0, gen=None):
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
-def test_gemm_exact_layouts(pg, dtype, ak, bk):
+@pytest.mark.parametrize("kfull", [False, True])
+def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull):
     """Small-integer operands: every product and partial sum is exact in bf16/fp32, so any
     fragment-layout or transposed-read mistake shows as a wrong integer.  A and B are
     asymmetric; sizes leave ragged M/N/K tails."""
     g = torch.Generator().manual_seed(1)
     epc = 4 if dtype == torch.float32 else 8
     M, N, K = 136 + epc, 200, 72 + epc
+    if kfull:  # whole k-tiles: the bf16 direct-to-LDS kernel (ragged K takes the register-staged one)
+        K = 192
     if not ak:
         M = 144
     if not bk:
@@ -62,6 +65,8 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk):
     B = torch.randint(-3, 4, (N, K), generator=g).float()
     A[:, 0] += torch.arange(M) % 5
     B[:, 1] -= torch.arange(N) % 7
+    A[:, K - 1] += torch.arange(M) % 3
+    B[:, K // 2] += torch.arange(N) % 4
     ref = A.double() @ B.double().T
     Ad = (A if ak else A.T.contiguous()).to(dtype).to(DEV)
     Bd = (B if bk else B.T.contiguous()).to(dtype).to(DEV)
@@ -217,6 +222,28 @@ def test_softmax_family(pg, dtype, S):
     close(Pdot2[:, :, :S], rP, dtype)
     if ld > S:
         assert float(Sbar[:, :, S:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S", [40, 64, 200, 512, 497])
+def test_fused_attention_forward(pg, S):
+    """Flash-style forward vs eager attention (HF eager_attention_forward) in fp64 on the same
+    bf16-rounded q, k, v; ragged S, masked keys, a fully visible row."""
+    g = torch.Generator().manual_seed(70 + S)
+    B, nh = 2, 3
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, dtype=torch.bfloat16, gen=g)
+    qkv[:, :H] *= 2.0  # sharper softmax
+    mask = torch.ones(B, S)
+    mask[0, S - 9:] = 0
+    mask[1, 5] = 0
+    q, k, v = (qkv[:, i * H:(i + 1) * H].double().view(B, S, nh, 64).transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(2, 3) * 0.125 + O.extended_mask(mask, torch.float64)
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, H)
+    for m in (mask, None):
+        if m is None:
+            ref = (torch.softmax(q @ k.transpose(2, 3) * 0.125, -1) @ v).transpose(1, 2).reshape(B * S, H)
+        out = pg.ops.attention_fwd(qkv.to(torch.bfloat16).to(DEV), None if m is None else m.to(DEV), B, S, nh)
+        close(out, ref, torch.bfloat16)
 
 
 # ----------------------------------------------------------------------------- sampler
