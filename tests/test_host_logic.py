@@ -1,0 +1,121 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares; host
+logic of generate.py / tokenizer / optimizer range merging / trainer helpers (no GPU compute)."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pgload
+from oracle import protbert_cpu as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pg():
+    return pgload.load()
+
+
+def test_library_exports_every_declared_symbol(pg):
+    import ctypes
+    text = open(os.path.join(ROOT, "include", "protgen_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", text)))
+    assert len(declared) >= 45
+    lib = ctypes.CDLL(os.path.join(ROOT, "protgen-gan_amd", "libprotgen_hip.so"))
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    from protgen_gan_amd import _lib
+    assert set(_lib.SIGNATURES) == set(declared), set(_lib.SIGNATURES) ^ set(declared)
+    assert _lib.lib.pg_abi_version() == 1
+    assert _lib.lib.pg_strerror(-2).decode().startswith("pointer")
+
+
+def test_parameter_layout_matches_protbert(pg):
+    import ctypes
+    from protgen_gan_amd import _lib
+    cfg = pg.ProtBertConfig()
+    c = cfg.to_c()
+    total = _lib.lib.pg_param_total(ctypes.byref(c))
+    n = sum(int(np.prod(O.param_shape(O.BertCfg(), k))) for k in O.param_names(O.BertCfg()))
+    assert n == 419_933_214 - 0  # ProtBERT parameter count (tied decoder weight counted once)
+    assert n <= total <= n + 8 * 500
+    # Q, K, V weights are adjacent: one [3H,H] matrix
+    o = [_lib.lib.pg_param_offset_layer(ctypes.byref(c), 3, w) for w in (_lib.L_WQ, _lib.L_WK, _lib.L_WV)]
+    assert o[1] - o[0] == 1024 * 1024 and o[2] - o[1] == 1024 * 1024
+    assert all(_lib.lib.pg_param_offset_layer(ctypes.byref(c), 0, w) % 8 == 0 for w in range(16))
+    assert _lib.lib.pg_head_total(1024) == 672_641
+    assert _lib.lib.pg_workspace_bytes(ctypes.byref(c), 1, 8, 512) > 0
+    assert _lib.lib.pg_stash_bytes(ctypes.byref(c), 1, 8, 512) > 5e9
+
+
+def test_models_refuse_cpu(pg):
+    with pytest.raises(RuntimeError):
+        pg.ProtBertForMaskedLM(pg.ProtBertConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                                 intermediate_size=256, max_position_embeddings=64), device="cpu")
+
+
+def test_generate_py_host_helpers(pg, tmp_path):
+    from protgen_gan_amd import generate as G
+    f = tmp_path / "seqs.txt"
+    f.write_text("ACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWY\n\nAC DE\n" + "A" * 700 + "\nMKVLAAGIVGLLLAQPSRAEDTPKGGSWMKVLAAG\n")
+    assert G.load_length_distribution(str(f), max_len=600, min_len=30) == [40, 35]
+    assert G.load_seed_sequences(str(f), max_len=600, min_len=30)[1].startswith("MKVL")
+    with pytest.raises(ValueError):
+        G.load_length_distribution(str(f), max_len=20, min_len=10)
+    with pytest.raises(FileNotFoundError):
+        G.safe_local_from_pretrained(str(tmp_path / "missing"), "cuda")
+    os.makedirs(tmp_path / "empty")
+    with pytest.raises(FileNotFoundError):
+        G.safe_local_from_pretrained(str(tmp_path / "empty"), "cuda")
+    assert G.derive_out_prefix("run_a/epoch_3/") == "run_a_epoch_3"
+    assert G.derive_out_prefix("protbert_base") == "protbert_base"
+    os.environ.pop("SOURCE_DIR", None)
+    with pytest.raises(EnvironmentError):
+        G.resolve_model_path("x/epoch_1")
+    os.environ["SOURCE_DIR"] = "/data/src"
+    assert G.resolve_model_path("x/epoch_1") == ("/data/src/checkpoints/x/epoch_1/generator_bert", "trained")
+    assert G.resolve_model_path("finetuned_protbert")[1] == "finetuned"
+    # builders: same tensors as the oracle's restatement of generate.py:92-127
+    ids, attn = G.build_fully_masked_batch([5, 0, 9], 2, 3, 4, 0, "cpu")
+    rid, rattn = O.build_fully_masked_batch([5, 0, 9])
+    assert torch.equal(ids, rid) and torch.equal(attn, rattn)
+    tok = pg.ProtTokenizer()
+    seqs = ["ACDEFGHIKLMNPQ", "MKV", "XUBZO"]
+    ids, attn = G.build_seeded_batch(seqs, tok, 0.1, 2, 3, 4, 0, "cpu", random.Random(5))
+    rid, rattn = O.build_seeded_batch(seqs, O.ProtTokenizer(), 0.1, random.Random(5))
+    assert torch.equal(ids, rid) and torch.equal(attn, rattn)
+
+
+def test_tokenizer(pg, tmp_path):
+    tok = pg.ProtTokenizer()
+    assert (tok.pad_token_id, tok.unk_token_id, tok.cls_token_id, tok.sep_token_id, tok.mask_token_id) == (0, 1, 2, 3, 4)
+    assert len(tok) == 30
+    assert tok.encode("A C J", add_special_tokens=True) == [2, 6, 23, 1, 3]
+    assert tok.decode([2, 5, 4, 25, 0, 3, 1, 9], skip_special_tokens=True) == "L X E"
+    tok.save_pretrained(str(tmp_path))
+    t2 = pg.ProtTokenizer.from_pretrained(str(tmp_path), do_lower_case=False)
+    assert t2.vocab == tok.vocab
+
+
+def test_trainer_helpers(pg):
+    from protgen_gan_amd import train as T
+    rng = random.Random(3)
+    ls = [T.sample_sequence_length([100, 480, 500], rng=rng) for _ in range(200)]
+    assert max(ls) <= 500 and min(ls) >= 90
+    # the fill schedule of the trainers: ten iterations, the tenth fills everything
+    rate, n, last = 0.9, 0, None
+    while rate > 0:
+        n, last = n + 1, rate
+        rate = max(0, rate - 0.1)
+    assert n == 10 and last <= 0.1 and not (0.10000000000000014 <= 0.1)
+    b = T.synthetic_real_batch(3, [30, 40], 64, "cpu", random.Random(1), torch.Generator().manual_seed(1))
+    assert b["input_ids"].shape == (3, 64) and b["attention_mask"].dtype == torch.float32
+    assert bool((b["input_ids"][:, 0] == 2).all())
+
+
+def test_adamw_range_merge(pg):
+    from protgen_gan_amd.optim import _merge_ranges
+    assert _merge_ranges([(0, 10), (16, 20), (100, 120), (10, 16)]) == [[0, 20], [100, 120]]
