@@ -229,11 +229,11 @@ template <typename T> __device__ __forceinline__ float gelu_d1_epi(float x);
 template <> __device__ __forceinline__ float gelu_d1_epi<float>(float x) { return gelu_d1(x); }
 template <> __device__ __forceinline__ float gelu_d1_epi<bf16_t>(float x) { return gelu_d1_fast(x); }
 
-template <typename T, typename TC>
-__device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[4][4], const GemmArgs& g, TC* Cp, int bm, int bn, int wr,
-                                                       int wc, int lane) {
-  const int n0 = bn + wc * 64 + 4 * (lane >> 4);
-  const int m0 = bm + wr * 64 + (lane & 15);
+template <typename T, typename TC, int MI>
+__device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], const GemmArgs& g, TC* Cp, int m_base, int n_base,
+                                                       int lane) {
+  const int n0 = n_base + 4 * (lane >> 4);
+  const int m0 = m_base + (lane & 15);
   float bv[4][4];
   if (g.bias) {
 #pragma unroll
@@ -247,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[4][4], const
   const T* aux = reinterpret_cast<const T*>(g.aux);
   const T* res = reinterpret_cast<const T*>(g.residual);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const long m = m0 + i * 16;
 #pragma unroll
     for (int jh = 0; jh < 4; jh += 2) {  // two column groups at a time keeps the live set small
@@ -307,21 +307,23 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[4][4], const
   }
 }
 
-template <typename T, typename TC>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], const GemmArgs& g, TC* Cp, int bm, int bn, int wr, int wc,
-                                              int lane) {
-  if (g.vec_ok && bm + BM <= g.M && bn + BN <= g.N) {
-    gemm_epilogue_interior<T, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
+// `interior`: the whole workgroup tile lies inside C and every operand is vector-aligned.
+// (m_base, n_base): first row / column of this wave's MI x 4 grid of 16x16 tiles.
+template <typename T, typename TC, int MI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArgs& g, TC* Cp, bool interior, int m_base,
+                                              int n_base, int lane) {
+  if (interior) {
+    gemm_epilogue_interior<T, TC, MI>(acc, g, Cp, m_base, n_base, lane);
     return;
   }
   const bool vec = g.vec_ok != 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = bm + wr * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < MI; ++i) {
+    const int m = m_base + i * 16 + (lane & 15);
     if (m >= g.M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = bn + wc * 64 + j * 16 + 4 * (lane >> 4);
+      const int n = n_base + j * 16 + 4 * (lane >> 4);
       if (n >= g.N) continue;
       const int nvalid = g.N - n < 4 ? g.N - n : 4;
       const bool v4 = vec && nvalid == 4;
@@ -334,13 +336,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], const GemmArgs
       if (g.act == PG_ACT_GELU) {
         if (g.aux) store4<T>(reinterpret_cast<T*>(g.aux) + (long)m * g.ldaux + n, v, v4, nvalid);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_epi<T>(v[e]);
       } else if (g.act == PG_ACT_MUL_DGELU) {
         float u[4];
         load4<T>(reinterpret_cast<const T*>(g.aux) + (long)m * g.ldaux + n, u, v4, nvalid);
         if (g.aux2) store4<T>(reinterpret_cast<T*>(g.aux2) + (long)m * g.ldaux + n, v, v4, nvalid);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_d1(u[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_d1_epi<T>(u[e]);
       }
       if (g.residual) {
         float r[4];
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue<T, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
+  gemm_epilogue<T, TC, 4>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
 }
 
 template <typename T, typename TC>
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(G
       glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
     }
   }
-  gemm_epilogue<bf16_t, TC>(acc, g, Cp, bm, bn, wr, wc, lane);
+  gemm_epilogue<bf16_t, TC, 4>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
 }
 
 template <typename TC, int NST>
@@ -649,12 +651,165 @@ int launch_glds(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
+
+// ---- narrow variant: 128 x 64 output tile (4 waves x 32 x 64), for N <= 64 attention products
+// (P V, dS K, dS^T Q, P^T dO ...) and as an option for grids that would otherwise leave CUs idle.
+// B tile: 64 rows of 128 bytes either way (k-major [n][k], or n-major [k][n] with the chunk
+// swizzle c ^ (k & 7)); two LDS buffers of 24 KiB.
+constexpr int NB_ELEMS = 64 * GBK;  // 4096 bf16 = 8 KiB
+
+template <bool KMAJOR>
+__device__ __forceinline__ void glds_stage_b64(const bf16_t* __restrict__ base, long ld, int n0, int n_max, int k0,
+                                               bf16_t* lds_tile, int wid, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = wid * 2 + j;            // wave instruction 0..7: 8 rows of 128 B
+    const int row = 8 * i + (lane >> 3);  // n (k-major) or k (n-major) inside the tile
+    const int c = (lane & 7) ^ (lane >> 3);
+    const bf16_t* src;
+    if (KMAJOR) {
+      int ng = n0 + row;
+      ng = ng < n_max ? ng : n_max - 1;
+      src = base + (long)ng * ld + k0 + c * 8;
+    } else {
+      int n = n0 + c * 8;
+      n = n <= n_max - 8 ? n : n_max - 8;
+      src = base + (long)(k0 + row) * ld + n;
+    }
+    __builtin_amdgcn_global_load_lds(src, lds_tile + i * 512, 16, 0, 0);
+  }
+}
+
+template <typename TC, bool AK, bool BK_>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) {
+  __shared__ __align__(16) bf16_t smem[2 * (GT_ELEMS + NB_ELEMS)];
+  const int z = blockIdx.z;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, gq = lane >> 4, qq = r >> 2, pp = r & 3;
+
+  // per-lane fragment offsets (bytes inside a tile)
+  unsigned offA[AK ? 2 : 4], offB[BK_ ? 2 : 8];
+  if constexpr (AK) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) offA[kk] = (unsigned)((wid * 32 + r) * 128 + (((kk * 4 + gq) ^ (r & 7)) << 4));
+  } else {
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = 8 * gq + qq + 4 * hi;
+        const int ch = wid * 4 + 2 * i + (pp >> 1);
+        offA[hi * 2 + i] = (unsigned)(k * 256 + ((ch ^ swz_m(k)) << 4) + 8 * (pp & 1));
+      }
+  }
+  if constexpr (BK_) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) offB[kk] = (unsigned)(r * 128 + (((kk * 4 + gq) ^ (r & 7)) << 4));
+  } else {
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 8 * gq + qq + 4 * hi;
+        const int c = 2 * j + (pp >> 1);
+        offB[hi * 4 + j] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+      }
+  }
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const unsigned smem_addr = lds_addr(smem);
+  constexpr int BUF = GT_ELEMS + NB_ELEMS;
+  const int nt = g.K / GBK;
+  glds_stage<AK>(A, g.lda, bm, g.M, 0, smem, wid, lane);
+  glds_stage_b64<BK_>(B, g.ldb, bn, g.N, 0, smem + GT_ELEMS, wid, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+      bf16_t* na = smem + ((t + 1) & 1) * BUF;
+      glds_stage<AK>(A, g.lda, bm, g.M, (t + 1) * GBK, na, wid, lane);
+      glds_stage_b64<BK_>(B, g.ldb, bn, g.N, (t + 1) * GBK, na + GT_ELEMS, wid, lane);
+    }
+    const unsigned la = smem_addr + (t & 1) * BUF * 2;
+    const unsigned lb = la + GT_ELEMS * 2;
+    u32x4 af[2][2], bf[2][4];  // [kk][tile]
+    if constexpr (AK) {
+      af[0][0] = lds_read_b128<0>(la + offA[0]);
+      af[0][1] = lds_read_b128<2048>(la + offA[0]);
+      af[1][0] = lds_read_b128<0>(la + offA[1]);
+      af[1][1] = lds_read_b128<2048>(la + offA[1]);
+    } else {
+#define PG_A_TR(KK, I)                                                         \
+      {                                                                        \
+        u32x2 lo = lds_read_tr_b64<KK * 8192>(la + offA[I]);                  \
+        u32x2 hi = lds_read_tr_b64<KK * 8192>(la + offA[2 + I]);              \
+        af[KK][I] = (u32x4){lo[0], lo[1], hi[0], hi[1]};                      \
+      }
+      PG_A_TR(0, 0) PG_A_TR(0, 1) PG_A_TR(1, 0) PG_A_TR(1, 1)
+#undef PG_A_TR
+    }
+    if constexpr (BK_) {
+#define PG_B_K(KK)                                        \
+      bf[KK][0] = lds_read_b128<0>(lb + offB[KK]);        \
+      bf[KK][1] = lds_read_b128<2048>(lb + offB[KK]);     \
+      bf[KK][2] = lds_read_b128<4096>(lb + offB[KK]);     \
+      bf[KK][3] = lds_read_b128<6144>(lb + offB[KK]);
+      PG_B_K(0) PG_B_K(1)
+#undef PG_B_K
+    } else {
+#define PG_B_TR(KK, J)                                                         \
+      {                                                                        \
+        u32x2 lo = lds_read_tr_b64<KK * 4096>(lb + offB[J]);                  \
+        u32x2 hi = lds_read_tr_b64<KK * 4096>(lb + offB[4 + J]);              \
+        bf[KK][J] = (u32x4){lo[0], lo[1], hi[0], hi[1]};                      \
+      }
+      PG_B_TR(0, 0) PG_B_TR(0, 1) PG_B_TR(0, 2) PG_B_TR(0, 3) PG_B_TR(1, 0) PG_B_TR(1, 1) PG_B_TR(1, 2) PG_B_TR(1, 3)
+#undef PG_B_TR
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[kk][j]),
+                                                              __builtin_bit_cast(bf16x8_t, af[kk][i]), acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+  gemm_epilogue<bf16_t, TC, 2>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + 64 <= g.N, bm + wid * 32, bn, lane);
+}
+
+template <typename TC>
+int launch_glds_n64(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((d->N + 63) / 64, (d->M + BM - 1) / BM, d->batch);
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_n64_kernel<TC, true, true>), grid, dim3(NTHREADS), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds_n64_kernel<TC, true, false>), grid, dim3(NTHREADS), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_n64_kernel<TC, false, true>), grid, dim3(NTHREADS), 0, st, a);
+  else hipLaunchKernelGGL((gemm_glds_n64_kernel<TC, false, false>), grid, dim3(NTHREADS), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 128x128 grid has <= 256 workgroups, 0 = never
+
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
 
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
+  if (key == 1) { g_gemm_narrow = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 
@@ -712,8 +867,12 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   int rc = PG_ERR_ARG;
   const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
                     (d->b_kmajor || d->N >= 8);
-  if (fast) {
-    const long blocks = (long)grid.x * grid.y * grid.z;
+  const long blocks128 = (long)grid.x * grid.y * grid.z;
+  if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
+    if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
+    else rc = launch_glds_n64<bf16_t>(d, a, st);
+  } else if (fast) {
+    const long blocks = blocks128;
     const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
     if (deep) {
       if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);

@@ -16,6 +16,8 @@ shapes = [  # name, M, N, K, ak, bk, out
     ("dgu  NN", T, 4096, 1024, True, False, torch.bfloat16),
     ("dh   NN", T, 1024, 4096, True, False, torch.bfloat16),
     ("dx   NN", T, 1024, 3072, True, False, torch.bfloat16),
+    ("pv   NN", 512, 64, 512, True, False, torch.bfloat16),
+    ("dk   TN", 512, 64, 512, False, False, torch.bfloat16),
     ("dW1  TN", 4096, 1024, T, False, False, torch.float32),
     ("dW2  TN", 1024, 4096, T, False, False, torch.float32),
     ("dWo  TN", 1024, 1024, T, False, False, torch.float32),
@@ -29,7 +31,8 @@ for name, M, N, K, ak, bk, od in shapes:
     res = {}
     for rnd in range(3):
         for path in (0, 2, 4):
-            lib.pg_tune(0, path)
+            lib.pg_tune(0, path if path else 1)
+            lib.pg_tune(1, 2 if path == 0 else 1)
             for _ in range(3):
                 pg.ops.gemm(A, B, C, a_kmajor=ak, b_kmajor=bk)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,7 +43,7 @@ for name, M, N, K, ak, bk, od in shapes:
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / n * 1e3
             res.setdefault(path, []).append(us)
-    lib.pg_tune(0, 1)
+    lib.pg_tune(0, 1); lib.pg_tune(1, 1)
     fl = 2.0 * M * N * K
     r0, r1, r2 = min(res[0]), min(res[2]), min(res[4])
-    print(f"{name} M{M} N{N} K{K}: staged {r0:7.1f} us {fl/r0/1e6:6.0f} TF | glds2 {r1:7.1f} us {fl/r1/1e6:6.0f} TF | glds4 {r2:7.1f} us {fl/r2/1e6:6.0f} TF")
+    print(f"{name} M{M} N{N} K{K}: n64 {r0:7.1f} us {fl/r0/1e6:6.0f} TF | glds2 {r1:7.1f} us {fl/r1/1e6:6.0f} TF | glds4 {r2:7.1f} us {fl/r2/1e6:6.0f} TF")

@@ -48,7 +48,8 @@ def rnd(*shape, dtype=torch.float32, scale=1.0, gen=None):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("kfull", [False, True])
-def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull):
+@pytest.mark.parametrize("narrow", [False, True])
+def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull, narrow):
     """Small-integer operands: every product and partial sum is exact in bf16/fp32, so any
     fragment-layout or transposed-read mistake shows as a wrong integer.  A and B are
     asymmetric; sizes leave ragged M/N/K tails."""
@@ -61,6 +62,8 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull):
         M = 144
     if not bk:
         N = 208
+    if narrow:  # N <= 64: the 128x64-tile kernel (bf16, whole k-tiles)
+        N = 56
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     B = torch.randint(-3, 4, (N, K), generator=g).float()
     A[:, 0] += torch.arange(M) % 5
