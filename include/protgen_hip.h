@@ -149,6 +149,10 @@ int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float*
  * + keymask) V straight from the packed [T][3H] QKV buffer, bf16 only, S <= 2048. */
 int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
                      int64_t ld_qkv, int64_t ld_ctx, void* stream);
+/* Same, additionally writing the probabilities P (activation dtype, [B*heads][S][pg_score_ld(S)],
+ * zeros in the padding columns) that the backward and gradient-penalty passes consume. */
+int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
+                       int64_t ld_qkv, int64_t ld_ctx, void* stream);
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */

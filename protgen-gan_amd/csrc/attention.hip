@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   // [buffer][K|V] tiles, then the additive key mask (fp32) of this batch row.  One array only:
   // a second __shared__ object would make the compiler drain the LDS-DMA before LDS reads.
   __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
-  const int bh = blockIdx.y;
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;  // the query tiles of one head share an XCD's L2
   const int b = bh / heads, h = bh % heads;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const bf16_t* K = Q + H;
   const bf16_t* V = Q + 2 * H;
   const float* mrow = mask ? mask + (long)b * S : nullptr;
-  const int q0 = blockIdx.x * QB + wid * 32;
+  const int q0 = qt * QB + wid * 32;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32kk + 8g .. +8]
   bf16x8_t qf[2][2];
@@ -253,6 +254,212 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// Training-pass variant: the same products, but the normalised probabilities P (bf16,
+// [B*heads][S][ldS], zeros in the padding columns) are written once for the backward and the
+// gradient-penalty passes.  Two sweeps over the keys: the first computes each query row's
+// max and sum (Q K^T only), the second recomputes the scores, writes P and accumulates P V.
+// That replaces an fp32 score matrix round trip (GEMM store, softmax load/store, GEMM load).
+__global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
+                                                             bf16_t* __restrict__ P, bf16_t* __restrict__ ctx, int S, int ldS,
+                                                             int heads, long ld_qkv, long ld_ctx) {
+  __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* Q = qkv + (long)b * S * ld_qkv + h * 64;
+  const bf16_t* K = Q + H;
+  const bf16_t* V = Q + 2 * H;
+  const float* mrow = mask ? mask + (long)b * S : nullptr;
+  const int q0 = qt * QB + wid * 32;
+
+  bf16x8_t qf[2][2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    int q = q0 + qg * 16 + r;
+    q = q < S ? q : S - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 v = *reinterpret_cast<const uint4*>(Q + (long)q * ld_qkv + kk * 32 + 8 * g);
+      qf[qg][kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  {
+    float* ml = reinterpret_cast<float*>(smem + 4 * TILE);
+    const int s_pad = ((S + KT - 1) / KT) * KT;
+    for (int k = threadIdx.x; k < s_pad; k += 256) {
+      float a = 0.f;
+      if (k >= S) a = -INFINITY;
+      else if (mrow) a = (1.0f - mrow[k]) * -FLT_MAX;
+      ml[k] = a;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  unsigned koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  unsigned voff[2][4];
+  {
+    const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int k = 4 * g + qq + 16 * hi;
+        const int c = 2 * d + (pp >> 1);
+        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+      }
+  }
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const unsigned mask_addr = smem_addr + 4 * TILE * 2;
+  const int nt = (S + KT - 1) / KT;
+
+  // scores of one key tile for both query groups, scaled and masked
+  auto scores = [&](unsigned ka, int t, f32x4 (&s)[2][4]) {
+    u32x4 mraw[4];
+    const unsigned ma = mask_addr + (unsigned)((t * KT + 4 * g) * 4);
+    mraw[0] = rd128<0>(ma);
+    mraw[1] = rd128<64>(ma);
+    mraw[2] = rd128<128>(ma);
+    mraw[3] = rd128<192>(ma);
+    u32x4 kf[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[0][kk] = rd128<0>(ka + koff[kk]);
+      kf[1][kk] = rd128<2048>(ka + koff[kk]);
+      kf[2][kk] = rd128<4096>(ka + koff[kk]);
+      kf[3][kk] = rd128<6144>(ka + koff[kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][0]), qf[qg][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[blk][1]), qf[qg][1], a, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = a[e] * 0.125f + __uint_as_float(mraw[blk][e]);
+        s[qg][blk] = a;
+      }
+  };
+
+  // ---- sweep 1: row max and sum
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  stage_tile(K, ld_qkv, 0, S, smem, wid, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) stage_tile(K, ld_qkv, (t + 1) * KT, S, smem + ((t + 1) & 1) * 2 * TILE, wid, lane);
+    f32x4 s[2][4];
+    scores(smem_addr + (t & 1) * 4 * TILE, t, s);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[qg][blk][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qg], mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += __expf(s[qg][blk][e] - m_new);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      l_run[qg] = l_run[qg] * __expf(m_run[qg] - m_new) + sum;
+      m_run[qg] = m_new;
+    }
+    __syncthreads();
+  }
+  const float inv_l[2] = {1.0f / l_run[0], 1.0f / l_run[1]};
+
+  // ---- sweep 2: P and P V
+  f32x4 o[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage_tile(K, ld_qkv, 0, S, smem, wid, lane);
+  stage_tile(V, ld_qkv, 0, S, smem + TILE, wid, lane);
+  __syncthreads();
+  bf16_t* Pz = P + (long)bh * S * ldS;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+      bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      stage_tile(K, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
+      stage_tile(V, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+    }
+    const unsigned ka = smem_addr + (t & 1) * 4 * TILE;
+    const unsigned va = ka + 2 * TILE;
+    f32x4 s[2][4];
+    scores(ka, t, s);
+    u32x2 vlo[2][4], vhi[2][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      vlo[0][d] = rdtr<0>(va + voff[0][d]);
+      vhi[0][d] = rdtr<0>(va + voff[1][d]);
+      vlo[1][d] = rdtr<4096>(va + voff[0][d]);
+      vhi[1][d] = rdtr<4096>(va + voff[1][d]);
+    }
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int q = q0 + qg * 16 + r;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        float pv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pv[e] = __expf(s[qg][blk][e] - m_run[qg]) * inv_l[qg];
+          s[qg][blk][e] = pv[e];
+        }
+        if (q < S) VecIO<bf16_t, 4>::store(Pz + (long)q * ldS + t * KT + blk * 16 + 4 * g, pv);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p8[e] = (__bf16)s[qg][2 * s2][e];
+          p8[4 + e] = (__bf16)s[qg][2 * s2 + 1][e];
+        }
+        pf[qg][s2] = p8;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 vv = (u32x4){vlo[s2][d][0], vlo[s2][d][1], vhi[s2][d][0], vhi[s2][d][1]};
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    if (q >= S) continue;
+    bf16_t* dst = ctx + ((long)b * S + q) * ld_ctx + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float v[4] = {o[qg][d][0], o[qg][d][1], o[qg][d][2], o[qg][d][3]};
+      VecIO<bf16_t, 4>::store(dst + d * 16, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
@@ -263,5 +470,16 @@ extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, v
   dim3 grid((S + QB - 1) / QB, B * heads);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, S,
                      heads, (long)ld_qkv, (long)ld_ctx);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
+                                  int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!qkv || !ctx || !P || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)P) & 7)) return PG_ERR_ALIGN;
+  dim3 grid((S + QB - 1) / QB, B * heads);
+  hipLaunchKernelGGL(attn_fwd_p_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
+                     (bf16_t*)ctx, S, pg_score_ld(S), heads, (long)ld_qkv, (long)ld_ctx);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }

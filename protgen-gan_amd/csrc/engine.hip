@@ -271,6 +271,9 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
     if (!stash && dtype == PG_BF16 && S <= 2048) {
       // nothing is kept for a backward: fused attention, no score matrix in HBM
       CK(pg_attention_fwd(dtype, s.qkv, mask, s.ctx, B, S, d.nh, 3 * H, H, st));
+    } else if (stash && dtype == PG_BF16 && S <= 2048) {
+      // fused attention that also writes P once for the backward passes
+      CK(pg_attention_fwd_p(dtype, s.qkv, mask, s.ss, s.ctx, B, S, d.nh, 3 * H, H, st));
     } else {
       // scores = Q K^T / 8
       CK(g.bat(d, s.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,

@@ -582,12 +582,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 template <typename TC, bool AK, bool BK_, int NST>
 __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(GemmArgs g) {
   __shared__ __align__(16) bf16_t smem[NST * 2 * GT_ELEMS];  // [buffer][A|B][16 KiB]
-  const int z = blockIdx.z;
+  const int gxy = gridDim.x * gridDim.y;
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+  const int z = lid / gxy, txy = lid % gxy;
   const int zo = z / g.batch_inner, zi = z % g.batch_inner;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int bm = (txy / gridDim.x) * BM, bn = (txy % gridDim.x) * BN;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wid >> 1, wc = wid & 1;
@@ -683,12 +685,14 @@ __device__ __forceinline__ void glds_stage_b64(const bf16_t* __restrict__ base, 
 template <typename TC, bool AK, bool BK_>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) {
   __shared__ __align__(16) bf16_t smem[2 * (GT_ELEMS + NB_ELEMS)];
-  const int z = blockIdx.z;
+  const int gxy = gridDim.x * gridDim.y;
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+  const int z = lid / gxy, txy = lid % gxy;
   const int zo = z / g.batch_inner, zi = z % g.batch_inner;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * 64;
+  const int bm = (txy / gridDim.x) * BM, bn = (txy % gridDim.x) * 64;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, gq = lane >> 4, qq = r >> 2, pp = r & 3;

@@ -57,6 +57,15 @@ __device__ __forceinline__ float gelu_d1_fast(float x) {
   return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so hardware ids b and
+// b + 8 share an L2.  This bijection hands every XCD a contiguous range of logical ids, so
+// neighbouring tiles (same A rows / same B columns / same attention head) meet in one L2.
+// Placement is a speed assumption only; nothing depends on it for correctness.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

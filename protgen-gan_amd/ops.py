@@ -195,3 +195,13 @@ def attention_fwd(qkv, mask, B, S, heads):
     check(lib.pg_attention_fwd(dt_code(qkv.dtype), qkv.data_ptr(), ptr(mask), ctx.data_ptr(), B, S, heads, qkv.stride(0),
                                ctx.stride(0), stream()), "pg_attention_fwd")
     return ctx
+
+
+def attention_fwd_p(qkv, mask, B, S, heads):
+    """As attention_fwd, also returning P [B*heads, S, score_ld(S)]."""
+    H = heads * 64
+    ctx = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
+    P = torch.empty(B * heads, S, score_ld(S), dtype=qkv.dtype, device=qkv.device)
+    check(lib.pg_attention_fwd_p(dt_code(qkv.dtype), qkv.data_ptr(), ptr(mask), P.data_ptr(), ctx.data_ptr(), B, S, heads,
+                                 qkv.stride(0), ctx.stride(0), stream()), "pg_attention_fwd_p")
+    return ctx, P

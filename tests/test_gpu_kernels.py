@@ -247,6 +247,12 @@ def test_fused_attention_forward(pg, S):
             ref = (torch.softmax(q @ k.transpose(2, 3) * 0.125, -1) @ v).transpose(1, 2).reshape(B * S, H)
         out = pg.ops.attention_fwd(qkv.to(torch.bfloat16).to(DEV), None if m is None else m.to(DEV), B, S, nh)
         close(out, ref, torch.bfloat16)
+        out2, P = pg.ops.attention_fwd_p(qkv.to(torch.bfloat16).to(DEV), None if m is None else m.to(DEV), B, S, nh)
+        close(out2, ref, torch.bfloat16)
+        pref = torch.softmax(q @ k.transpose(2, 3) * 0.125 + (O.extended_mask(m, torch.float64) if m is not None else 0), -1)
+        close(P[:, :, :S], pref.reshape(B * nh, S, S), torch.bfloat16)
+        if P.shape[2] > S:
+            assert float(P[:, :, S:].float().abs().max()) == 0.0
 
 
 # ----------------------------------------------------------------------------- sampler
