@@ -153,6 +153,11 @@ int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, i
  * zeros in the padding columns) that the backward and gradient-penalty passes consume. */
 int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
                        int64_t ld_qkv, int64_t ld_ctx, void* stream);
+/* First half of the attention backward from the stored P: dS = P*(dO V^T - <dO,O>) (written,
+ * same layout as P) and dQ = dS K / 8 (written to dq + head offset, row stride ld_dq).  The
+ * second half is two GEMMs: dK = dS^T Q / 8, dV = P^T dO. */
+int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dq,
+                        int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream);
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */

@@ -460,6 +460,189 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
   }
 }
 
+// First half of the attention backward, consuming the stored probabilities P:
+//   dP = dO V^T ; delta_q = <dO_q, O_q> ; dS = P * (dP - delta) ; dQ = dS K / 8
+// in the same query-on-the-lane formulation as the forward (dP^T = V dO^T has the layout of
+// the score tile; dS, rounded to bf16, is the B operand of dQ^T = K^T dS^T as it stands).
+// dS is written out ([B*heads][S][ldS], like P): the second half (dK = dS^T Q / 8,
+// dV = P^T dO) is two 128x64-tile GEMMs over it, and the gradient penalty keeps it.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
+                                                              const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                              bf16_t* __restrict__ dS, bf16_t* __restrict__ dq, int S, int ldS,
+                                                              int heads, long ld_qkv, long ld_ctx, long ld_dq) {
+  __shared__ __align__(16) bf16_t smem[4 * TILE];
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* K = qkv + (long)b * S * ld_qkv + h * 64 + H;
+  const bf16_t* V = K + H;
+  const int q0 = qt * QB + wid * 32;
+
+  // dO fragments (B operand of dP^T = V dO^T) and delta_q = <dO_q, O_q>
+  bf16x8_t df[2][2];
+  float delta[2];
+  int qrow[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    int q = q0 + qg * 16 + r;
+    q = q < S ? q : S - 1;
+    qrow[qg] = q;
+    float acc = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const long o = ((long)b * S + q) * ld_ctx + h * 64 + kk * 32 + 8 * g;
+      uint4 dv = *reinterpret_cast<const uint4*>(dctx + o);
+      uint4 ov = *reinterpret_cast<const uint4*>(ctx + o);
+      df[qg][kk] = __builtin_bit_cast(bf16x8_t, dv);
+      const bf16_t* de = reinterpret_cast<const bf16_t*>(&dv);
+      const bf16_t* oe = reinterpret_cast<const bf16_t*>(&ov);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf16_bits_to_f32(de[e]) * bf16_bits_to_f32(oe[e]);
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    delta[qg] = acc;
+  }
+
+  unsigned koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  unsigned voff[2][4];
+  {
+    const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int k = 4 * g + qq + 16 * hi;
+        const int c = 2 * d + (pp >> 1);
+        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+      }
+  }
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const int nt = (S + KT - 1) / KT;
+  const bf16_t* Pz = P + (long)bh * S * ldS;
+  bf16_t* dSz = dS + (long)bh * S * ldS;
+
+  f32x4 o[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // P of the current tile is fetched one iteration ahead, before that iteration's LDS-DMA is
+  // issued, so its wait never drains the DMA ring.
+  uint2 pcur[2][4], pnext[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_tile(V, ld_qkv, 0, S, smem, wid, lane);          // slot 0: V (k-major in d for dP^T = V dO^T)
+  stage_tile(K, ld_qkv, 0, S, smem + TILE, wid, lane);   // slot 1: K (transposed reads for dQ^T = K^T dS^T)
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+      bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      stage_tile(V, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
+      stage_tile(K, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+    }
+    const unsigned va = smem_addr + (t & 1) * 4 * TILE;
+    const unsigned ka = va + 2 * TILE;
+    u32x4 vf[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      vf[0][kk] = rd128<0>(va + koff[kk]);
+      vf[1][kk] = rd128<2048>(va + koff[kk]);
+      vf[2][kk] = rd128<4096>(va + koff[kk]);
+      vf[3][kk] = rd128<6144>(va + koff[kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 dp[2][4];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][0]), df[qg][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][1]), df[qg][1], a, 0, 0, 0);
+        dp[qg][blk] = a;
+      }
+    u32x2 klo[2][4], khi[2][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      klo[0][d] = rdtr<0>(ka + voff[0][d]);
+      khi[0][d] = rdtr<0>(ka + voff[1][d]);
+      klo[1][d] = rdtr<4096>(ka + voff[0][d]);
+      khi[1][d] = rdtr<4096>(ka + voff[1][d]);
+    }
+    bf16x8_t sf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int q = q0 + qg * 16 + r;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const uint2 pr = pcur[qg][blk];
+        const float p0 = __uint_as_float(pr.x << 16), p1 = __uint_as_float(pr.x & 0xffff0000u);
+        const float p2 = __uint_as_float(pr.y << 16), p3 = __uint_as_float(pr.y & 0xffff0000u);
+        float ds[4] = {p0 * (dp[qg][blk][0] - delta[qg]), p1 * (dp[qg][blk][1] - delta[qg]),
+                       p2 * (dp[qg][blk][2] - delta[qg]), p3 * (dp[qg][blk][3] - delta[qg])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[qg][blk][e] = ds[e];
+        if (q < S) VecIO<bf16_t, 4>::store(dSz + (long)q * ldS + t * KT + blk * 16 + 4 * g, ds);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p8[e] = (__bf16)dp[qg][2 * s2][e];
+          p8[4 + e] = (__bf16)dp[qg][2 * s2 + 1][e];
+        }
+        sf[qg][s2] = p8;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 kv = (u32x4){klo[s2][d][0], klo[s2][d][1], khi[s2][d][0], khi[s2][d][1]};
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, kv);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    if (q >= S) continue;
+    bf16_t* dst = dq + ((long)b * S + q) * ld_dq + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float v[4] = {o[qg][d][0] * 0.125f, o[qg][d][1] * 0.125f, o[qg][d][2] * 0.125f, o[qg][d][3] * 0.125f};
+      VecIO<bf16_t, 4>::store(dst + d * 16, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
@@ -481,5 +664,20 @@ extern "C" int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask,
   dim3 grid((S + QB - 1) / QB, B * heads);
   hipLaunchKernelGGL(attn_fwd_p_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
                      (bf16_t*)ctx, S, pg_score_ld(S), heads, (long)ld_qkv, (long)ld_ctx);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
+                                   void* dq, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
+                                   void* stream) {
+  if (!qkv || !P || !ctx || !dctx || !dS || !dq || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 8) || (ld_dq % 4)) return PG_ERR_ALIGN;
+  if ((((uintptr_t)qkv) | ((uintptr_t)ctx) | ((uintptr_t)dctx)) & 15) return PG_ERR_ALIGN;
+  if ((((uintptr_t)P) | ((uintptr_t)dS) | ((uintptr_t)dq)) & 7) return PG_ERR_ALIGN;
+  dim3 grid((S + QB - 1) / QB, B * heads);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                     (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, pg_score_ld(S), heads, (long)ld_qkv,
+                     (long)ld_ctx, (long)ld_dq);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }

@@ -391,11 +391,15 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     // dctx = da Wo
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
-    CK(g.bat(d, a.ctx, true, H, false, off(s.qkv, 2 * H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f,
-             0.f));
-    CK(pg_softmax_bwd(dtype, w.sc0, s.ss, a.ss, (int)d.Z, S, st));
-    CK(g.bat(d, a.ss, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, a.qkv, dtype, 3 * H, false, S, 64, S,
-             0.125f, 0.f));
+    if (dtype == PG_BF16 && S <= 2048) {
+      CK(pg_attention_bwd_dq(dtype, s.qkv, s.ss, s.ctx, a.ctx, a.ss, a.qkv, B, S, d.nh, 3 * H, H, 3 * H, st));
+    } else {
+      CK(g.bat(d, a.ctx, true, H, false, off(s.qkv, 2 * H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+               1.f, 0.f));
+      CK(pg_softmax_bwd(dtype, w.sc0, s.ss, a.ss, (int)d.Z, S, st));
+      CK(g.bat(d, a.ss, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, a.qkv, dtype, 3 * H, false, S, 64, S,
+               0.125f, 0.f));
+    }
     CK(g.bat(d, a.ss, false, d.ldS, true, s.qkv, false, 3 * H, false, off(a.qkv, H, es), dtype, 3 * H, false, S, 64, S,
              0.125f, 0.f));
     CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
