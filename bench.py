@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-sample", type=int, default=16)
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="(kernel A/B runs) forwarded to pg_tune before the first step")
     args = ap.parse_args()
 
     import pgload
@@ -74,6 +76,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    for kv in args.tune:
+        k, v = kv.split("=")
+        lib.pg_tune(int(k), int(v))
 
     cfg = pg.ProtBertConfig(num_hidden_layers=args.layers)
     generator = pg.Generator(pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=dtype).init_random(seed=0))

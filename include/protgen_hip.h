@@ -101,7 +101,7 @@ int pg_gemm(const pg_gemm_desc* d, void* stream);
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
-int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids) */
+int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always) */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 

@@ -628,7 +628,8 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(G
     }
     for (int t = 0; t < nt; ++t) {
       const int ahead = nt - 1 - t;  // tiles issued after tile t that may remain in flight
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (NST >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1)%NST is free again
@@ -653,6 +654,117 @@ int launch_glds(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
+
+// ---- wide variant: 256 x 256 output tile, 512 threads (8 waves as 2 x 4, 128 x 64 per wave) --
+// A 128x128 tile moves 256 operand rows through L2 per 128x128 outputs; at the matrix-core rate
+// that is more than the L2 -> LDS path delivers, so the large-N products (N >= 2048: the
+// feed-forward expansion, the fused QKV projection and the input gradient of the contraction)
+// use a tile with twice the reuse.  One workgroup per CU, two waves per SIMD, two 64 KiB LDS
+// stages (A and B each as two independent 128-row sub-tiles in the layouts above, so staging and
+// fragment addressing are shared with the 128x128 kernel).  A wave keeps 128 accumulator
+// registers and walks a k-tile in four chunks (k-step x row half), each chunk's fragment reads
+// issued one chunk ahead of the MFMAs that consume them.
+constexpr int NT256 = 512;
+int g_gemm_dbg = 0;
+
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
+}
+
+__device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const u32x4 (&a)[4], const u32x4 (&b)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, a[i]),
+                                                               acc[i0 + i][j], 0, 0, 0);
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void glds256_compute(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa_lo, const FragOff<AK>& fa_hi,
+                                                const FragOff<BK_>& fb, f32x4 (&acc)[8][4]) {
+  constexpr int NA = AK ? 4 : 8, NB = BK_ ? 4 : 8;  // LDS reads per group of four fragments
+  u32x4 b0[4], b1[4], a00[4], a01[4], a10[4], a11[4];
+  read_frags<BK_, 0>(b_addr, fb, b0);
+  read_frags<AK, 0>(a_addr, fa_lo, a00);
+  read_frags<AK, 0>(a_addr, fa_hi, a01);
+  lgkm_wait<NA>();
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_4x4(acc, 0, a00, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<BK_, 1>(b_addr, fb, b1);
+  read_frags<AK, 1>(a_addr, fa_lo, a10);
+  lgkm_wait<NA + NB>();
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_4x4(acc, 4, a01, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<AK, 1>(a_addr, fa_hi, a11);
+  lgkm_wait<NA>();
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_4x4(acc, 0, a10, b1);
+  lgkm_wait<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_4x4(acc, 4, a11, b1);
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void glds256_stage(const bf16_t* A, const bf16_t* B, const GemmArgs& g, int bm, int bn, int k0,
+                                              bf16_t* stage, int wid, int lane) {
+  const int half = wid >> 2, w4 = wid & 3;  // waves 0-3 fill the first 128-row sub-tiles, 4-7 the second
+  glds_stage<AK>(A, g.lda, bm + half * 128, g.M, k0, stage + half * GT_ELEMS, w4, lane);
+  glds_stage<BK_>(B, g.ldb, bn + half * 128, g.N, k0, stage + (2 + half) * GT_ELEMS, w4, lane);
+}
+
+template <typename TC, bool AK, bool BK_, int DBG = 0>
+__global__ __launch_bounds__(NT256, 1) void gemm_glds256_kernel(GemmArgs g) {
+  __shared__ __align__(16) bf16_t smem[2 * 4 * GT_ELEMS];  // [stage][A0 A1 B0 B1][16 KiB]
+  const int gxy = gridDim.x * gridDim.y;
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+  const int z = lid / gxy, txy = lid % gxy;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  const int bm = (txy / gridDim.x) * 256, bn = (txy % gridDim.x) * 256;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / GBK;
+  const FragOff<AK> fa_lo = frag_offsets<AK>(0, lane), fa_hi = frag_offsets<AK>(1, lane);
+  const FragOff<BK_> fb = frag_offsets<BK_>(wc & 1, lane);
+  const unsigned smem_addr = lds_addr(smem);
+  const unsigned a_off = wr * 2 * GT_ELEMS, b_off = (2 + (wc >> 1)) * 2 * GT_ELEMS;  // bytes inside a stage
+
+  glds256_stage<AK, BK_>(A, B, g, bm, bn, 0, smem, wid, lane);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; the other stage is no longer being read
+    if (t + 1 < nt && !(DBG & 1)) glds256_stage<AK, BK_>(A, B, g, bm, bn, (t + 1) * GBK, smem + ((t + 1) & 1) * 4 * GT_ELEMS, wid, lane);
+    const unsigned st = smem_addr + (t & 1) * 8 * GT_ELEMS;
+    if constexpr (!(DBG & 2)) glds256_compute<AK, BK_>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc);
+  }
+  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
+}
+
+template <typename TC>
+int launch_glds256(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((d->N + 255) / 256, (d->M + 255) / 256, d->batch);
+  if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 1) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 1>), grid, dim3(NT256), 0, st, a);
+  else if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 2) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 2>), grid, dim3(NT256), 0, st, a);
+  else if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 3) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 3>), grid, dim3(NT256), 0, st, a);
+  else if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true>), grid, dim3(NT256), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, false>), grid, dim3(NT256), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, false, true>), grid, dim3(NT256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_glds256_kernel<TC, false, false>), grid, dim3(NT256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
 
 // ---- narrow variant: 128 x 64 output tile (4 waves x 32 x 64), for N <= 64 attention products
 // (P V, dS K, dS^T Q, P^T dO ...) and as an option for grids that would otherwise leave CUs idle.
@@ -807,6 +919,8 @@ int launch_glds_n64(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
 
 int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 128x128 grid has <= 256 workgroups, 0 = never
 
+int g_gemm_wide = 1;  // 1 = 256x256 tiles for large-N products with enough tiles to cover the chip, 2 = always, 0 = never
+
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -814,6 +928,8 @@ int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring dep
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
+  if (key == 2) { g_gemm_wide = value; return PG_OK; }
+  if (key == 3) { g_gemm_dbg = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 
@@ -875,10 +991,17 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
     if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
     else rc = launch_glds_n64<bf16_t>(d, a, st);
+  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide == 1 && d->N >= 2048 &&
+                      (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 160))) {
+    if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
+    else rc = launch_glds256<bf16_t>(d, a, st);
   } else if (fast) {
     const long blocks = blocks128;
     const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
-    if (deep) {
+    if (g_gemm_path == 5) {
+      if (d->c_dtype == PG_F32) rc = launch_glds<float, 5>(d, a, grid, st);
+      else rc = launch_glds<bf16_t, 5>(d, a, grid, st);
+    } else if (deep) {
       if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);
       else rc = launch_glds<bf16_t, 4>(d, a, grid, st);
     } else {

@@ -105,8 +105,12 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
     gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device)
-    real_scores = critic(real_data, attention_mask=attn_mask_real)
-    fake_scores = critic(fake, attention_mask=fake_mask)
+    # real and fake rows go through the encoder as one 2B-row batch (rows are independent, so the
+    # scores equal those of two separate calls); the larger GEMMs fill the chip better
+    B = real_data.size(0)
+    scores = critic(torch.cat([real_data, fake], dim=0),
+                    attention_mask=torch.cat([attn_mask_real.to(fake_mask.dtype), fake_mask], dim=0))
+    real_scores, fake_scores = scores[:B], scores[B:]
     c_loss = critic_loss(real_scores, fake_scores, gp, hp.lambda_gp)
     c_loss.backward()
     if grad_sync is not None:

@@ -14,9 +14,10 @@ Ws = [(torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16) for
 bias = torch.randn(N, device=dev)
 C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
 aux = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
-lib.pg_tune(0, 2)
+wide = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+lib.pg_tune(2, wide)
 for label, kw in (("plain", {}), ("bias", {"bias": bias}), ("bias+gelu", {"bias": bias, "act": 1}), ("bias+gelu+aux", {"bias": bias, "act": 1, "aux": aux})):
-    for chunk in range(6):
+    for chunk in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         n = 300

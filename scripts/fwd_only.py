@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pgload
 pg = pgload.load()
+for kv in sys.argv[2:]:
+    pg._lib.lib.pg_tune(*map(int, kv.split("=")))
 dev = "cuda"
 cfg = pg.ProtBertConfig()
 m = pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=torch.bfloat16).init_random(0)

@@ -77,6 +77,63 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull, narrow):
     assert torch.equal(out.cpu().double(), ref)
 
 
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("shape", [(520, 776, 192), (256, 256, 64), (264, 520, 320)])
+def test_gemm_wide_tile_exact(pg, ak, bk, shape):
+    """The 256x256-tile bf16 kernel (forced; normally only large-N products take it): exact
+    integers over several tiles with ragged M and N edges, all four operand layouts, and both
+    output types."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = shape
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[:, 0] += torch.arange(M) % 5
+    B[:, 1] -= torch.arange(N) % 7
+    A[:, K - 1] += torch.arange(M) % 3
+    B[:, K // 2] += torch.arange(N) % 4
+    ref = A.double() @ B.double().T
+    Ad = (A if ak else A.T.contiguous()).to(torch.bfloat16).to(DEV)
+    Bd = (B if bk else B.T.contiguous()).to(torch.bfloat16).to(DEV)
+    pg._lib.lib.pg_tune(2, 2)
+    try:
+        out = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
+        out16 = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, alpha=1.0 / 64)
+    finally:
+        pg._lib.lib.pg_tune(2, 1)
+    assert torch.equal(out.cpu().double(), ref)
+    close(out16, ref / 64, torch.bfloat16)
+
+
+def test_gemm_wide_tile_epilogues(pg):
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(12)
+    M, N, Kd = 520, 512, 256
+    A, B = rnd(M, Kd, dtype=dtype, gen=g), rnd(N, Kd, dtype=dtype, scale=0.05, gen=g)
+    bias = torch.randn(N, generator=g)
+    res = rnd(M, N, dtype=dtype, gen=g)
+    U = rnd(M, N, dtype=dtype, gen=g)
+    Ad, Bd = A.to(dtype).to(DEV), B.to(dtype).to(DEV)
+    base = A.double() @ B.double().T
+    pg._lib.lib.pg_tune(2, 2)
+    try:
+        out = pg.ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(dtype).to(DEV))
+        close(out, base + bias.double() + res.double(), dtype)
+        aux = torch.empty(M, N, dtype=dtype, device=DEV)
+        out = pg.ops.gemm(Ad, Bd, bias=bias.to(DEV), act=pg._lib.PG_ACT_GELU, aux=aux)
+        close(aux, base + bias.double(), dtype)
+        close(out, K.gelu(base + bias.double()), dtype)
+        aux2 = torch.empty(M, N, dtype=dtype, device=DEV)
+        out = pg.ops.gemm(Ad, Bd, act=pg._lib.PG_ACT_MUL_DGELU, aux=U.to(dtype).to(DEV), aux2=aux2)
+        close(aux2, base, dtype)
+        close(out, base * K.gelu_d1(U.double()), dtype)
+        C0 = torch.randn(M, N, generator=g)
+        Cd = C0.clone().to(DEV)
+        pg.ops.gemm(Ad, Bd, Cd, alpha=0.5, beta=1.0)
+        close(Cd, C0.double() + 0.5 * base, dtype)
+    finally:
+        pg._lib.lib.pg_tune(2, 1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(pg, dtype):
     g = torch.Generator().manual_seed(2)

@@ -250,6 +250,42 @@ def test_critic_step_vs_oracle_fresh_inputs(pg):
         rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
 
 
+def test_train_critic_update_matches_oracle(pg):
+    """train.critic_update (real and fake rows batched through the encoder as one 2B-row pass,
+    alpha drawn from the CPU generator as loss.py:15 does) against the oracle's critic step."""
+    from protgen_gan_amd import train as T
+    c, P, PC, C, _, critic = build(pg, "tiny", torch.float32)
+    g = torch.Generator().manual_seed(78)
+    B, S = 3, 40
+    real = torch.randint(5, 25, (B, S), generator=g)
+    fake = torch.randint(5, 25, (B, S), generator=g)
+    real[:, 0] = fake[:, 0] = O.CLS
+    rm = torch.ones(B, S)
+    rm[1, 33:] = 0
+    real[1, 33:] = O.PAD
+    fake[2, 25:] = O.PAD
+    fm = (fake != O.PAD).long()
+    torch.manual_seed(4242)
+    alpha = torch.rand(B, 1, 1)
+    loss, gp, rs, fs, grads = O.critic_step_grads(PC, C, c, real, fake, rm, fm, alpha, 5.0)
+
+    class NoStep:
+        def zero_grad(self):
+            critic.zero_grad(set_to_none=True)
+
+        def step(self):
+            pass
+
+    torch.manual_seed(4242)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    l_h = T.critic_update(critic, NoStep(), d(real), d(rm), d(fake), T.GanHyper(lambda_gp=5.0))
+    rel_close(l_h.item(), loss.numpy(), 2e-4, "loss")
+    named = dict(critic.named_parameters())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for n, gref in grads.items():
+        rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
+
+
 def test_generator_step_backward_touches_only_critic(pg):
     """fully_masked_train.py:349-352: g_loss.backward() reaches no generator parameter."""
     c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
