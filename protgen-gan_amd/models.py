@@ -39,11 +39,28 @@ class Generator(nn.Module):
         Exp(1) noise has shape [B*S, V] exactly like the draw `torch.multinomial` makes; it
         is taken from the device's global generator unless `noise` is given (tests inject
         the reference's draw).  Ties in the top-k are broken towards the lowest index."""
+        return self._fill_step(input_ids, attention_mask, [(0, input_ids.shape[0], float(temperature))], keep_percent,
+                               current_rate, noise)
+
+    @torch.no_grad()
+    def generate_groups(self, input_ids, attention_mask, groups, keep_percent=0.1, current_rate=None, noise=None):
+        """The same fill step for several independent batches stacked along dim 0, one encoder
+        pass for all of them.  `groups` = [(row_begin, row_end, temperature), ...] covers the
+        rows; each group is sampled at its own temperature, exactly as separate generate()
+        calls on the row slices would (rows never interact: attention is per sequence and the
+        top-k commit is per row)."""
+        return self._fill_step(input_ids, attention_mask, [(int(a), int(b), float(t)) for a, b, t in groups],
+                               keep_percent, current_rate, noise)
+
+    def _fill_step(self, input_ids, attention_mask, groups, keep_percent, current_rate, noise):
         m: ProtBertForMaskedLM = self.protbert
         ids = m._check_ids(input_ids)
         inplace = ids.data_ptr() == input_ids.data_ptr()
         B, S = ids.shape
         V = m.config.vocab_size
+        covered = sorted((a, b) for a, b, _ in groups)
+        if covered[0][0] != 0 or covered[-1][1] != B or any(x[1] != y[0] for x, y in zip(covered, covered[1:])):
+            raise ValueError("groups must partition the rows of input_ids")
         mask = m._mask01(attention_mask, B, S)
         hidden, _ = m._encode(ids, None, mask, want_stash=False)
         logits = m.lm_logits(hidden).view(B * S, V)
@@ -51,7 +68,13 @@ class Generator(nn.Module):
             noise = torch.empty(B * S, V, dtype=torch.float32, device=ids.device).exponential_(1.0)
         else:
             noise = noise.to(device=ids.device, dtype=torch.float32).contiguous().view(B * S, V)
-        pred, conf = ops.sample_tokens(logits, noise, float(temperature))
+        if len(groups) == 1:
+            pred, conf = ops.sample_tokens(logits, noise, groups[0][2])
+        else:
+            pred = torch.empty(B * S, dtype=torch.long, device=ids.device)
+            conf = torch.empty(B * S, dtype=torch.float32, device=ids.device)
+            for a, b, t in groups:
+                ops.sample_tokens(logits[a * S:b * S], noise[a * S:b * S], t, pred=pred[a * S:b * S], conf=conf[a * S:b * S])
         fill_all = current_rate is not None and current_rate <= 0.1
         counts = torch.empty(B, 2, dtype=torch.int32, device=ids.device)
         ops.commit_topk(ids, pred, conf, float(keep_percent), fill_all, self.mask_token_id, self.pad_token_id,

@@ -161,10 +161,15 @@ def mlm_decode(t, word, bias):
     return logits
 
 
-def sample_tokens(logits, noise, temperature: float):
+def sample_tokens(logits, noise, temperature: float, pred=None, conf=None):
     T, V = logits.shape
-    pred = torch.empty(T, dtype=torch.int64, device=logits.device)
-    conf = torch.empty(T, dtype=torch.float32, device=logits.device)
+    assert logits.is_contiguous() and noise.is_contiguous() and noise.shape == logits.shape
+    if pred is None:
+        pred = torch.empty(T, dtype=torch.int64, device=logits.device)
+    if conf is None:
+        conf = torch.empty(T, dtype=torch.float32, device=logits.device)
+    assert pred.is_contiguous() and conf.is_contiguous() and pred.numel() == T and conf.numel() == T
+    assert pred.dtype == torch.int64 and conf.dtype == torch.float32
     check(lib.pg_sample_tokens(logits.data_ptr(), noise.data_ptr(), float(temperature), T, V, pred.data_ptr(),
                                conf.data_ptr(), stream()), "pg_sample_tokens")
     return pred, conf

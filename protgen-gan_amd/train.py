@@ -96,15 +96,70 @@ def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: 
     return ids
 
 
+def fill_temperatures(hp: GanHyper) -> List[float]:
+    """The per-iteration temperatures one blind-mode fake batch draws (fully_masked_train.py:223):
+    one CPU `torch.rand(1)` per pass of the `while rate > 0` loop, whose length is fixed by the
+    rate schedule (the early exit can only trigger once every mask is gone, i.e. after the
+    fill-all pass that ends the schedule)."""
+    temps, rate = [], hp.initial_masking_rate
+    while rate > 0:
+        temps.append(hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp))
+        rate = max(0, rate - hp.iteration_fill_rate)
+    return temps
+
+
+def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequence[int]],
+                          temps_per_batch: Sequence[Sequence[float]], hp: GanHyper, device, mask_id=4, cls_id=2,
+                          sep_id=3, pad_id=0) -> List[torch.Tensor]:
+    """Several blind-mode fake batches filled together: the generator's weights do not change
+    between them, so their fill passes run as one stacked batch (one encoder pass per fill
+    iteration for all of them) instead of one batch after the other.  Each batch keeps what a
+    separate generate_fake_batch call would give it: its own template width (positions beyond
+    it are excluded from attention, positions inside it follow `ids != MASK`), its own
+    temperature per iteration, and padding to max_len at the end."""
+    widths = [max(ls) for ls in lengths_per_batch]
+    S = max(widths)
+    rows = sum(len(ls) for ls in lengths_per_batch)
+    ids = torch.full((rows, S), pad_id, dtype=torch.long)
+    inside = torch.zeros(rows, S, dtype=torch.bool)
+    spans, r = [], 0
+    for ls, w in zip(lengths_per_batch, widths):
+        spans.append((r, r + len(ls)))
+        for L in ls:
+            ids[r, :L] = mask_id
+            ids[r, 0] = cls_id
+            ids[r, L - 1] = sep_id
+            inside[r, :w] = True
+            r += 1
+    ids, inside = ids.to(device), inside.to(device)
+    rate, it = hp.initial_masking_rate, 0
+    while rate > 0:
+        attn = ((ids != mask_id) & inside).long()
+        groups = [(a, b, temps[it]) for (a, b), temps in zip(spans, temps_per_batch)]
+        ids = generator.generate_groups(ids, attn, groups, keep_percent=hp.iteration_fill_rate, current_rate=rate)
+        if generator.fill_shapes and generator.fill_shapes[-1] == (rows, S):
+            # throughput bookkeeping counts each batch at its own width, not the stacked one
+            generator.fill_shapes[-1:] = [(b - a, w) for (a, b), w in zip(spans, widths)]
+        rate = max(0, rate - hp.iteration_fill_rate)
+        it += 1
+        if int(generator.last_counts[:, 1].sum().item()) == 0:
+            break
+    out = []
+    for (a, b), w in zip(spans, widths):
+        x = ids[a:b, :min(w, hp.max_len)]
+        out.append(F.pad(x, (0, hp.max_len - x.size(1)), value=pad_id).contiguous())
+    return out
+
+
 def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, fake_data, hp: GanHyper,
-                  pad_id=0, grad_sync: Optional[Callable[[], None]] = None) -> torch.Tensor:
+                  pad_id=0, grad_sync: Optional[Callable[[], None]] = None, alpha=None) -> torch.Tensor:
     """fully_masked_train.py:297-326 / 10p_train.py:327-338.  `grad_sync` (data-parallel
     gradient averaging) runs between backward and the optimizer step.  Returns c_loss
     (device scalar; the caller decides when to synchronise for logging)."""
     critic_optimizer.zero_grad()
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
-    gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device)
+    gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device, alpha=alpha)
     # real and fake rows go through the encoder as one 2B-row batch (rows are independent, so the
     # scores equal those of two separate calls); the larger GEMMs fill the chip better
     B = real_data.size(0)
@@ -133,17 +188,40 @@ def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0) -> torc
 
 def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                    real_batches: List[dict], length_pool: Sequence[int], hp: GanHyper, batch_size: int, device,
-                   rng=random, grad_sync=None):
+                   rng=random, grad_sync=None, stacked_generation: bool = True):
     """One iteration of the blind-mode training loop: n_critic critic updates (each with a
-    fresh fake batch) followed by one generator update on `gen_batch_blind` fakes."""
+    fresh fake batch) followed by one generator update on `gen_batch_blind` fakes.
+
+    Nothing updates the generator inside the iteration (its optimizer step is a no-op, see
+    generator_update), so with `stacked_generation` all n_critic + 1 fake batches are filled
+    up front as one stacked batch.  The host random draws are made in the order the
+    one-after-the-other loop makes them (lengths from `rng`; temperatures and the
+    gradient-penalty alpha from the CPU torch generator)."""
+    real_batches = real_batches[:hp.n_critic]
+    if not stacked_generation:
+        c_sum = None
+        for batch in real_batches:
+            fake = generate_fake_batch(generator, batch_size, length_pool, hp, device, rng=rng)
+            c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
+                              grad_sync=grad_sync)
+            c_sum = c if c_sum is None else c_sum + c
+        fake = generate_fake_batch(generator, hp.gen_batch_blind, length_pool, hp, device, rng=rng)
+        g = generator_update(critic, gen_optimizer, fake)
+        return c_sum / hp.n_critic, g
+    lengths, temps, alphas = [], [], []
+    for batch in real_batches:
+        lengths.append([sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size)])
+        temps.append(fill_temperatures(hp))
+        alphas.append(torch.rand(batch["input_ids"].size(0), 1, 1))
+    lengths.append([sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(hp.gen_batch_blind)])
+    temps.append(fill_temperatures(hp))
+    fakes = generate_fake_batches(generator, lengths, temps, hp, device)
     c_sum = None
-    for batch in real_batches[:hp.n_critic]:
-        fake = generate_fake_batch(generator, batch_size, length_pool, hp, device, rng=rng)
+    for batch, fake, alpha in zip(real_batches, fakes, alphas):
         c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
-                          grad_sync=grad_sync)
+                          grad_sync=grad_sync, alpha=alpha)
         c_sum = c if c_sum is None else c_sum + c
-    fake = generate_fake_batch(generator, hp.gen_batch_blind, length_pool, hp, device, rng=rng)
-    g = generator_update(critic, gen_optimizer, fake)
+    g = generator_update(critic, gen_optimizer, fakes[-1])
     return c_sum / hp.n_critic, g
 
 

@@ -286,6 +286,63 @@ def test_train_critic_update_matches_oracle(pg):
         rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
 
 
+def _blind_template(lengths, width):
+    ids = torch.full((len(lengths), width), O.PAD, dtype=torch.long)
+    for i, L in enumerate(lengths):
+        ids[i, :L] = O.MASK
+        ids[i, 0] = O.CLS
+        ids[i, L - 1] = O.SEP
+    return ids
+
+
+def test_generate_groups_matches_separate_calls(pg):
+    """Two blind-mode batches of different template widths filled as one stacked batch give,
+    in fp32 and with the same Exp(1) draws, exactly the tokens of two separate generate()
+    calls, fill iteration after fill iteration."""
+    c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
+    V = c.vocab_size
+    g = torch.Generator().manual_seed(5)
+    wa, wb = 30, 40
+    a, b = _blind_template([30, 22], wa).to(DEV), _blind_template([40, 35, 28], wb).to(DEV)
+    st = torch.full((5, wb), O.PAD, dtype=torch.long, device=DEV)
+    st[:2, :wa], st[2:] = a, b
+    inside = torch.zeros(5, wb, dtype=torch.bool, device=DEV)
+    inside[:2, :wa] = True
+    inside[2:] = True
+    for rate in (0.9, 0.8, 0.1):
+        na = torch.empty(2 * wa, V).exponential_(1.0, generator=g)
+        nb = torch.empty(3 * wb, V).exponential_(1.0, generator=g)
+        ns = torch.empty(5, wb, V).exponential_(1.0, generator=g)
+        ns[:2, :wa], ns[2:] = na.view(2, wa, V), nb.view(3, wb, V)
+        a = gen.generate(a, (a != O.MASK).long(), temperature=0.9, keep_percent=0.3, current_rate=rate, noise=na)
+        ca = gen.last_counts.clone()
+        b = gen.generate(b, (b != O.MASK).long(), temperature=1.15, keep_percent=0.3, current_rate=rate, noise=nb)
+        cb = gen.last_counts.clone()
+        st = gen.generate_groups(st, ((st != O.MASK) & inside).long(), [(0, 2, 0.9), (2, 5, 1.15)], keep_percent=0.3,
+                                 current_rate=rate, noise=ns.view(5 * wb, V))
+        assert torch.equal(st[:2, :wa], a) and torch.equal(st[2:], b)
+        assert bool((st[:2, wa:] == O.PAD).all())
+        assert torch.equal(gen.last_counts, torch.cat([ca, cb]))
+    assert int(gen.last_counts[:, 0].sum()) > 0  # the fill-all pass committed something
+
+
+def test_stacked_blind_generation_shapes(pg):
+    from protgen_gan_amd import train as T
+    c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
+    hp = T.GanHyper(max_len=40)
+    lengths = [[12, 30, 25], [38, 9, 17], [20, 21]]
+    torch.manual_seed(3)
+    temps = [T.fill_temperatures(hp) for _ in lengths]
+    assert all(len(t) == 10 and all(hp.min_temp <= x <= hp.max_temp for x in t) for t in temps)
+    fakes = T.generate_fake_batches(gen, lengths, temps, hp, DEV)
+    for ls, f in zip(lengths, fakes):
+        assert f.shape == (len(ls), 40) and f.is_contiguous()
+        for L, row in zip(ls, f.cpu()):
+            assert int(row[0]) == O.CLS and int(row[L - 1]) == O.SEP
+            assert bool(((row[1:L - 1] >= 0) & (row[1:L - 1] < c.vocab_size)).all())
+            assert bool((row[L:] == O.PAD).all())
+
+
 def test_generator_step_backward_touches_only_critic(pg):
     """fully_masked_train.py:349-352: g_loss.backward() reaches no generator parameter."""
     c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
