@@ -96,12 +96,18 @@ typedef struct {
   int act;
 } pg_gemm_desc;
 int pg_gemm(const pg_gemm_desc* d, void* stream);
+/* Two unbatched products in one launch (results identical to pg_gemm(d0) then pg_gemm(d1)):
+ * the autograd backward of BertSelfOutput.dense and of the query/key/value Linears
+ * (modeling_bert.py:282-293, 111-136) yields two weight-gradient products at the same point,
+ * one of which alone covers a quarter of the chip.  Falls back to two launches when the two
+ * descriptors do not share dtype / layout or are not whole-k-tile bf16 products. */
+int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void* stream);
 /* Measurement aid (no reference counterpart): time every `sample_every`-th pg_gemm launch
  * with HIP events on its own stream.  pg_profile_end synchronises those events, stops the
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
-int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always) */
+int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1) */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 

@@ -128,6 +128,22 @@ struct G {
     d.aux2 = aux2; d.act = act;
     return pg_gemm(&d, st);
   }
+  // Two weight gradients dW += dY^T X (fp32 accumulate) in one launch.
+  int dw_pair(const void* dY0, long ld0, const void* X0, long ldx0, float* dW0, int No0, int Ni0, const void* dY1, long ld1,
+              const void* X1, long ldx1, float* dW1, int No1, int Ni1, int T) const {
+    pg_gemm_desc d[2];
+    memset(d, 0, sizeof(d));
+    const void* A[2] = {dY0, dY1}; const void* B[2] = {X0, X1}; float* C[2] = {dW0, dW1};
+    const long lda[2] = {ld0, ld1}, ldb[2] = {ldx0, ldx1};
+    const int M[2] = {No0, No1}, N[2] = {Ni0, Ni1};
+    for (int i = 0; i < 2; ++i) {
+      d[i].A = A[i]; d[i].B = B[i]; d[i].C = C[i]; d[i].dtype = dtype; d[i].c_dtype = PG_F32;
+      d[i].a_kmajor = 0; d[i].b_kmajor = 0; d[i].M = M[i]; d[i].N = N[i]; d[i].K = T;
+      d[i].lda = lda[i]; d[i].ldb = ldb[i]; d[i].ldc = N[i]; d[i].batch = 1; d[i].batch_inner = 1;
+      d[i].alpha = 1.f; d[i].beta = 1.f;
+    }
+    return pg_gemm_pair(&d[0], &d[1], st);
+  }
   // Batched over (b, head).  Operands living in a [T][ld] activation buffer are addressed with
   // (outer = S*ld, inner = 64); score-shaped operands with (outer = nh*S*ldS, inner = S*ldS).
   int bat(const Dims& dm, const void* A, bool ak, long lda, bool a_score, const void* B, bool bk, long ldb, bool b_score,
@@ -384,11 +400,8 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     CK(pg_layernorm_bwd(dtype, s.a, a.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, a.a,
                         grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
                         w.ln_partial, T, H, st));
-    if (grads) {
-      CK(g.run(a.a, false, H, s.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
-      CK(pg_colsum_acc(dtype, a.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
-    }
-    // dctx = da Wo
+    if (grads) CK(pg_colsum_acc(dtype, a.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
+    // dctx = da Wo   (dWo = da^T ctx waits for dWqkv below: 64 + 192 tiles fill the chip together)
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
     if (dtype == PG_BF16 && S <= 2048) {
@@ -405,7 +418,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              0.f));
     if (grads) {
-      CK(g.run(a.qkv, false, 3 * H, s.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
+      CK(g.dw_pair(a.a, H, s.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, a.qkv, 3 * H, s.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
       CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // dx = dqkv Wqkv + da
@@ -513,11 +526,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     CK(pg_layernorm_bwd2(dtype, s.a, t.a, a.h, w.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, w.a,
                          grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
                          w.ln_partial, T, H, st));
-    if (grads) {
-      CK(g.run(w.a, false, H, s.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
-      CK(g.run(a.a, false, H, t.ctx, false, H, pv.g(pv.lo(l, PG_L_WO)), PG_F32, H, H, H, T, 1.f, 1.f));
-      CK(pg_colsum_acc(dtype, w.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
-    }
+    if (grads) CK(pg_colsum_acc(dtype, w.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));  // the Wo products pair with the QKV ones below
     // ctxbar = abar Wo
     CK(g.run(w.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention second order
@@ -543,8 +552,8 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              1.f));
     if (grads) {
-      CK(g.run(w.qkv, false, 3 * H, s.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
-      CK(g.run(a.qkv, false, 3 * H, t.x, false, H, pv.g(pv.lo(l, PG_L_WQ)), PG_F32, H, 3 * H, H, T, 1.f, 1.f));
+      CK(g.dw_pair(w.a, H, s.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, w.qkv, 3 * H, s.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
+      CK(g.dw_pair(a.a, H, t.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, a.qkv, 3 * H, t.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
       CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // xbar = qkvbar Wqkv + abar

@@ -307,12 +307,78 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
   }
 }
 
+// bf16 output with 16-byte-aligned operands: the two lanes that hold columns 4g..4g+3 of the
+// 16x16 tiles j and j+1 (g = lane >> 4) first trade halves across 16-lane rows
+// (v_permlane16_swap), after which a lane owns eight consecutive columns of ONE tile: even g
+// keeps tile j, odd g tile j+1, columns 8*(g>>1)..+7.  Every access of the epilogue is then a
+// 16-byte vector and the number of store instructions, which is what bounds the store tail of a
+// workgroup that owns a whole CU, is halved.
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], const GemmArgs& g, bf16_t* Cp, int m_base,
+                                                          int n_base, int lane) {
+  const int gq = lane >> 4;
+  const int m0 = m_base + (lane & 15);
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
+#pragma unroll
+  for (int jh = 0; jh < 4; jh += 2) {
+    const int nn = n_base + (jh + (gq & 1)) * 16 + 8 * (gq >> 1);
+    float bv[8];
+    if (g.bias) {
+      VecIO<float, 4>::load(g.bias + nn, bv);
+      VecIO<float, 4>::load(g.bias + nn + 4, bv + 4);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long m = m0 + i * 16;
+      float v[8], u[8], r[8];
+      if (g.act == PG_ACT_MUL_DGELU) VecIO<bf16_t, 8>::load(aux + m * g.ldaux + nn, u);
+      if (res) VecIO<bf16_t, 8>::load(res + m * g.ldr + nn, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][jh][e]), __float_as_uint(acc[i][jh + 1][e]), false, false);
+        v[e] = __uint_as_float(sw[0]) * g.alpha + bv[e];
+        v[4 + e] = __uint_as_float(sw[1]) * g.alpha + bv[4 + e];
+      }
+      if (g.act == PG_ACT_GELU) {
+        if (g.aux) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux) + m * g.ldaux + nn, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      } else if (g.act == PG_ACT_MUL_DGELU) {
+        if (g.aux2) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux2) + m * g.ldaux + nn, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_d1_fast(u[e]);
+      }
+      if (res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (g.beta != 0.f) {
+        float c0[8];
+        VecIO<bf16_t, 8>::load(Cp + m * g.ldc + nn, c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
+      }
+      VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn, v);
+    }
+  }
+}
+
 // `interior`: the whole workgroup tile lies inside C and every operand is vector-aligned.
 // (m_base, n_base): first row / column of this wave's MI x 4 grid of 16x16 tiles.
 template <typename T, typename TC, int MI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArgs& g, TC* Cp, bool interior, int m_base,
                                               int n_base, int lane) {
   if (interior) {
+    if constexpr (sizeof(T) == 2 && sizeof(TC) == 2) {
+      if (g.vec_ok == 2) {
+        gemm_epilogue_interior_b8<MI>(acc, g, Cp, m_base, n_base, lane);
+        return;
+      }
+    }
     gemm_epilogue_interior<T, TC, MI>(acc, g, Cp, m_base, n_base, lane);
     return;
   }
@@ -580,16 +646,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 //          s_barrier (one barrier per k-tile), one workgroup per CU: for grids of about one
 //          workgroup per CU, where nothing else hides the HBM/L2 latency.
 template <typename TC, bool AK, bool BK_, int NST>
-__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(GemmArgs g) {
-  __shared__ __align__(16) bf16_t smem[NST * 2 * GT_ELEMS];  // [buffer][A|B][16 KiB]
-  const int gxy = gridDim.x * gridDim.y;
-  const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
-  const int z = lid / gxy, txy = lid % gxy;
-  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
-  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  const int bm = (txy / gridDim.x) * BM, bn = (txy % gridDim.x) * BN;
+__device__ __forceinline__ void glds_body(bf16_t* smem, const GemmArgs& g, const bf16_t* A, const bf16_t* B, TC* Cp, int bm, int bn) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wid >> 1, wc = wid & 1;
@@ -628,8 +685,7 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(G
     }
     for (int t = 0; t < nt; ++t) {
       const int ahead = nt - 1 - t;  // tiles issued after tile t that may remain in flight
-      if (NST >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1)%NST is free again
@@ -645,6 +701,37 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(G
   gemm_epilogue<bf16_t, TC, 4>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
 }
 
+
+template <typename TC, bool AK, bool BK_, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(GemmArgs g) {
+  __shared__ __align__(16) bf16_t smem[NST * 2 * GT_ELEMS];  // [buffer][A|B][16 KiB]
+  const int gxy = gridDim.x * gridDim.y;
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
+  const int z = lid / gxy, txy = lid % gxy;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
+  glds_body<TC, AK, BK_, NST>(smem, g, A, B, Cp, (txy / gridDim.x) * BM, (txy % gridDim.x) * BN);
+}
+
+// Two independent products of the same layout in one launch (unbatched): workgroups [0, nb0)
+// tile the first, the rest the second.  Used to pair a product that has too few tiles to cover
+// the chip (the attention-output weight gradient: 64 tiles) with one that is ready at the same
+// time (the QKV weight gradient: 192 tiles).
+struct GemmArgs2 { GemmArgs p0, p1; int nb0, gx0, gx1; };
+
+template <typename TC, bool AK, bool BK_, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_pair_kernel(GemmArgs2 a) {
+  __shared__ __align__(16) bf16_t smem[NST * 2 * GT_ELEMS];
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const bool second = lid >= a.nb0;
+  const GemmArgs& g = second ? a.p1 : a.p0;
+  const int txy = second ? lid - a.nb0 : lid, gx = second ? a.gx1 : a.gx0;
+  glds_body<TC, AK, BK_, NST>(smem, g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
+                              reinterpret_cast<TC*>(g.C), (txy / gx) * BM, (txy % gx) * BN);
+}
+
 template <typename TC, int NST>
 int launch_glds(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t st) {
   if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_kernel<TC, true, true, NST>), grid, dim3(NTHREADS), 0, st, a);
@@ -654,6 +741,15 @@ int launch_glds(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream_t
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
+
+template <typename TC, int NST>
+int launch_glds_pair(const pg_gemm_desc* d, const GemmArgs2& a, int blocks, hipStream_t st) {
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_pair_kernel<TC, true, true, NST>), dim3(blocks), dim3(NTHREADS), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds_pair_kernel<TC, true, false, NST>), dim3(blocks), dim3(NTHREADS), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds_pair_kernel<TC, false, true, NST>), dim3(blocks), dim3(NTHREADS), 0, st, a);
+  else hipLaunchKernelGGL((gemm_glds_pair_kernel<TC, false, false, NST>), dim3(blocks), dim3(NTHREADS), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
 
 // ---- wide variant: 256 x 256 output tile, 512 threads (8 waves as 2 x 4, 128 x 64 per wave) --
 // A 128x128 tile moves 256 operand rows through L2 per 128x128 outputs; at the matrix-core rate
@@ -680,39 +776,139 @@ __device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const u32x4
                                                                acc[i0 + i][j], 0, 0, 0);
 }
 
-template <bool AK, bool BK_>
-__device__ __forceinline__ void glds256_compute(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa_lo, const FragOff<AK>& fa_hi,
-                                                const FragOff<BK_>& fb, f32x4 (&acc)[8][4]) {
+// Per-lane byte offsets (from the workgroup's first operand row / column) of the four 1 KiB
+// pieces a wave copies of one 128-row sub-tile; the k-tile only moves the uniform base.
+template <bool KMAJOR>
+__device__ __forceinline__ void piece_offsets(long ld, int blk0, int half, int extent, int w4, int lane, unsigned (&off)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = w4 * 4 + j;
+    if constexpr (KMAJOR) {
+      const int c = (lane & 7) ^ (lane >> 3);
+      int rg = blk0 + half * 128 + 8 * i + (lane >> 3);
+      rg = rg < extent ? rg : extent - 1;
+      off[j] = (unsigned)(((long)(rg - blk0) * ld + c * 8) * 2);
+    } else {
+      const int k = 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ swz_m(k);
+      int m = blk0 + half * 128 + c * 8;
+      m = m <= extent - 8 ? m : extent - 8;
+      off[j] = (unsigned)(((long)k * ld + (m - blk0)) * 2);
+    }
+  }
+}
+
+__device__ __forceinline__ void mfma_row(f32x4 (&acc)[4], const u32x4& a, const u32x4 (&b)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, a), acc[j], 0, 0, 0);
+}
+
+// One k-tile of one wave: 64 MFMAs in four chunks (k-step x row half), each chunk's fragment
+// reads issued one chunk ahead.  With LOAD the wave's eight LDS-DMA pieces of the next k-tile
+// are issued one per four MFMAs inside the first two chunks: a piece holds the issuing wave for
+// tens of cycles, so a burst of eight at the top of the tile would idle the matrix pipe.  The
+// two waves that share a SIMD use opposite phases (PH: piece before / after its four MFMAs) so
+// one of them is always feeding the pipe.
+template <bool AK, bool BK_, int PH, bool LOAD, bool MATH>
+__device__ __forceinline__ void glds256_tile(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa_lo, const FragOff<AK>& fa_hi,
+                                             const FragOff<BK_>& fb, f32x4 (&acc)[8][4], const char* a_src, const char* b_src,
+                                             const unsigned (&aoff)[4], const unsigned (&boff)[4], bf16_t* a_dst, bf16_t* b_dst) {
   constexpr int NA = AK ? 4 : 8, NB = BK_ ? 4 : 8;  // LDS reads per group of four fragments
+  if constexpr (!MATH) {
+    if constexpr (LOAD) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(a_src + aoff[j], a_dst + j * 512, 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(b_src + boff[j], b_dst + j * 512, 16, 0, 0);
+    }
+    return;
+  }
   u32x4 b0[4], b1[4], a00[4], a01[4], a10[4], a11[4];
   read_frags<BK_, 0>(b_addr, fb, b0);
   read_frags<AK, 0>(a_addr, fa_lo, a00);
   read_frags<AK, 0>(a_addr, fa_hi, a01);
   lgkm_wait<NA>();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_4x4(acc, 0, a00, b0);
-  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if constexpr (LOAD && PH == 0) {
+      __builtin_amdgcn_global_load_lds(a_src + aoff[g], a_dst + g * 512, 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_row(acc[g], a00[g], b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LOAD && PH == 1) {
+      __builtin_amdgcn_global_load_lds(a_src + aoff[g], a_dst + g * 512, 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   read_frags<BK_, 1>(b_addr, fb, b1);
   read_frags<AK, 1>(a_addr, fa_lo, a10);
   lgkm_wait<NA + NB>();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_4x4(acc, 4, a01, b0);
-  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if constexpr (LOAD && PH == 0) {
+      __builtin_amdgcn_global_load_lds(b_src + boff[g], b_dst + g * 512, 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_row(acc[4 + g], a01[g], b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LOAD && PH == 1) {
+      __builtin_amdgcn_global_load_lds(b_src + boff[g], b_dst + g * 512, 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   read_frags<AK, 1>(a_addr, fa_hi, a11);
   lgkm_wait<NA>();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_4x4(acc, 0, a10, b1);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) mfma_row(acc[g], a10[g], b1);
+  __builtin_amdgcn_sched_barrier(0);
   lgkm_wait<0>();
   __builtin_amdgcn_sched_barrier(0);
-  mfma_4x4(acc, 4, a11, b1);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) mfma_row(acc[4 + g], a11[g], b1);
 }
 
-template <bool AK, bool BK_>
-__device__ __forceinline__ void glds256_stage(const bf16_t* A, const bf16_t* B, const GemmArgs& g, int bm, int bn, int k0,
-                                              bf16_t* stage, int wid, int lane) {
-  const int half = wid >> 2, w4 = wid & 3;  // waves 0-3 fill the first 128-row sub-tiles, 4-7 the second
-  glds_stage<AK>(A, g.lda, bm + half * 128, g.M, k0, stage + half * GT_ELEMS, w4, lane);
-  glds_stage<BK_>(B, g.ldb, bn + half * 128, g.N, k0, stage + (2 + half) * GT_ELEMS, w4, lane);
+template <bool AK, bool BK_, int PH, int DBG>
+__device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t* A, const bf16_t* B, int bm, int bn, bf16_t* smem,
+                                                 int wid, int lane, f32x4 (&acc)[8][4]) {
+  const int wr = wid >> 2, wc = wid & 3, w4 = wid & 3, half = wid >> 2;
+  const int nt = g.K / GBK;
+  const FragOff<AK> fa_lo = frag_offsets<AK>(0, lane), fa_hi = frag_offsets<AK>(1, lane);
+  const FragOff<BK_> fb = frag_offsets<BK_>(wc & 1, lane);
+  const unsigned smem_addr = lds_addr(smem);
+  const unsigned a_off = wr * 2 * GT_ELEMS, b_off = (2 + (wc >> 1)) * 2 * GT_ELEMS;  // bytes inside a stage
+  unsigned aoff[4], boff[4];
+  piece_offsets<AK>(g.lda, bm, half, g.M, w4, lane, aoff);
+  piece_offsets<BK_>(g.ldb, bn, half, g.N, w4, lane, boff);
+  // uniform source bases of k-tile 0 and their per-tile strides (bytes)
+  const char* a_src = reinterpret_cast<const char*>(AK ? A + (long)bm * g.lda : A + bm);
+  const char* b_src = reinterpret_cast<const char*>(BK_ ? B + (long)bn * g.ldb : B + bn);
+  const long a_step = AK ? GBK * 2 : (long)GBK * g.lda * 2, b_step = BK_ ? GBK * 2 : (long)GBK * g.ldb * 2;
+  const int dst0 = half * GT_ELEMS + w4 * 4 * 512;  // this wave's first piece inside a stage (A part; B is 2 sub-tiles on)
+
+  // k-tile 0 (nothing to overlap it with)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(a_src + aoff[j], smem + dst0 + j * 512, 16, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(b_src + boff[j], smem + 2 * GT_ELEMS + dst0 + j * 512, 16, 0, 0);
+  for (int t = 0; t < nt - 1; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; the other stage is no longer being read
+    a_src += a_step;
+    b_src += b_step;
+    const unsigned st = smem_addr + (t & 1) * 8 * GT_ELEMS;
+    bf16_t* nx = smem + ((t + 1) & 1) * 4 * GT_ELEMS + dst0;
+    glds256_tile<AK, BK_, PH, !(DBG & 1), !(DBG & 2)>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc, a_src, b_src, aoff, boff, nx,
+                                                     nx + 2 * GT_ELEMS);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const unsigned st = smem_addr + ((nt - 1) & 1) * 8 * GT_ELEMS;
+  glds256_tile<AK, BK_, PH, false, !(DBG & 2)>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc, a_src, b_src, aoff, boff, smem, smem);
 }
 
 template <typename TC, bool AK, bool BK_, int DBG = 0>
@@ -736,20 +932,9 @@ __global__ __launch_bounds__(NT256, 1) void gemm_glds256_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = g.K / GBK;
-  const FragOff<AK> fa_lo = frag_offsets<AK>(0, lane), fa_hi = frag_offsets<AK>(1, lane);
-  const FragOff<BK_> fb = frag_offsets<BK_>(wc & 1, lane);
-  const unsigned smem_addr = lds_addr(smem);
-  const unsigned a_off = wr * 2 * GT_ELEMS, b_off = (2 + (wc >> 1)) * 2 * GT_ELEMS;  // bytes inside a stage
-
-  glds256_stage<AK, BK_>(A, B, g, bm, bn, 0, smem, wid, lane);
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; the other stage is no longer being read
-    if (t + 1 < nt && !(DBG & 1)) glds256_stage<AK, BK_>(A, B, g, bm, bn, (t + 1) * GBK, smem + ((t + 1) & 1) * 4 * GT_ELEMS, wid, lane);
-    const unsigned st = smem_addr + (t & 1) * 8 * GT_ELEMS;
-    if constexpr (!(DBG & 2)) glds256_compute<AK, BK_>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc);
-  }
+  // waves w and w + 4 share a SIMD: opposite piece phases
+  if (wr == 0) glds256_mainloop<AK, BK_, 0, DBG>(g, A, B, bm, bn, smem, wid, lane, acc);
+  else glds256_mainloop<AK, BK_, 1, DBG>(g, A, B, bm, bn, smem, wid, lane, acc);
   gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
 }
 
@@ -921,6 +1106,8 @@ int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 
 
 int g_gemm_wide = 1;  // 1 = 256x256 tiles for large-N products with enough tiles to cover the chip, 2 = always, 0 = never
 
+int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte accesses only)
+int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -930,10 +1117,70 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
   if (key == 2) { g_gemm_wide = value; return PG_OK; }
   if (key == 3) { g_gemm_dbg = value; return PG_OK; }
+  if (key == 4) { g_gemm_ep8 = value; return PG_OK; }
+  if (key == 5) { g_gemm_pair = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 
+namespace {
+int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a);
+ProfEntry* prof_begin(int variant, double flops, hipStream_t st);
+}  // namespace
+
 extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
+  GemmArgs a;
+  const int prc = gemm_prepare(d, a);
+  if (prc != PG_OK) return prc;
+  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
+  hipStream_t st = (hipStream_t)stream;
+  ProfEntry* pe = prof_begin((d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0),
+                             2.0 * d->M * d->N * (double)d->K * d->batch, st);
+  int rc = PG_ERR_ARG;
+  const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
+                    (d->b_kmajor || d->N >= 8);
+  const long blocks128 = (long)grid.x * grid.y * grid.z;
+  if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
+    if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
+    else rc = launch_glds_n64<bf16_t>(d, a, st);
+  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide == 1 && d->N >= 2048 &&
+                      (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 160))) {
+    if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
+    else rc = launch_glds256<bf16_t>(d, a, st);
+  } else if (fast) {
+    const long blocks = blocks128;
+    const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
+    if (deep) {
+      if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);
+      else rc = launch_glds<bf16_t, 4>(d, a, grid, st);
+    } else {
+      if (d->c_dtype == PG_F32) rc = launch_glds<float, 2>(d, a, grid, st);
+      else rc = launch_glds<bf16_t, 2>(d, a, grid, st);
+    }
+  } else if (d->dtype == PG_BF16) {
+    if (d->c_dtype == PG_F32) rc = launch_layout<bf16_t, float>(d, a, grid, st);
+    else rc = launch_layout<bf16_t, bf16_t>(d, a, grid, st);
+  } else if (d->dtype == PG_F32) {
+    rc = launch_layout<float, float>(d, a, grid, st);
+  }
+  if (pe) hipEventRecord(pe->b, st);
+  return rc;
+}
+namespace {
+ProfEntry* prof_begin(int variant, double flops, hipStream_t st) {
+  if (g_prof.every <= 0) return nullptr;
+  ++g_prof.launches;
+  if (++g_prof.counter % g_prof.every != 0) return nullptr;
+  ProfEntry e;
+  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+  e.variant = variant;
+  e.flops = flops;
+  g_prof.entries.push_back(e);
+  ProfEntry* pe = &g_prof.entries.back();
+  hipEventRecord(pe->a, st);
+  return pe;
+}
+
+int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
   if (!d || !d->A || !d->B || !d->C) return PG_ERR_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->batch_inner <= 0) return PG_ERR_ARG;
   if (d->batch % d->batch_inner) return PG_ERR_ARG;
@@ -949,7 +1196,6 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (d->act == PG_ACT_MUL_DGELU && !d->aux) return PG_ERR_ARG;
   if (d->c_dtype != PG_F32 && d->c_dtype != d->dtype) return PG_ERR_ARG;
 
-  GemmArgs a;
   a.A = d->A; a.B = d->B; a.C = d->C;
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
@@ -967,53 +1213,46 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (d->bias) vec = vec && (((uintptr_t)d->bias) % 16 == 0);
   if (a.aux2) vec = vec && (((uintptr_t)a.aux2) % (4 * tsz) == 0);
   a.vec_ok = vec ? 1 : 0;
+  if (vec && d->dtype == PG_BF16 && d->c_dtype == PG_BF16) {  // 16-byte epilogue accesses possible?
+    bool v8 = (d->ldc % 8 == 0) && (d->sCo % 8 == 0) && (d->sCi % 8 == 0) && (((uintptr_t)d->C) % 16 == 0);
+    if (d->residual) v8 = v8 && (d->ldr % 8 == 0) && (((uintptr_t)d->residual) % 16 == 0);
+    if (d->aux) v8 = v8 && (d->ldaux % 8 == 0) && (((uintptr_t)d->aux) % 16 == 0);
+    if (a.aux2) v8 = v8 && (((uintptr_t)a.aux2) % 16 == 0);
+    if (v8 && g_gemm_ep8) a.vec_ok = 2;
+  }
 
-  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
+  return PG_OK;
+}
+}  // namespace
+
+
+extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void* stream) {
+  GemmArgs2 a;
+  int rc = gemm_prepare(d0, a.p0);
+  if (rc != PG_OK) return rc;
+  rc = gemm_prepare(d1, a.p1);
+  if (rc != PG_OK) return rc;
+  auto fast = [](const pg_gemm_desc* d) {
+    return d->dtype == PG_BF16 && d->K % GBK == 0 && d->batch == 1 && d->N > 64 && (d->a_kmajor || d->M >= 8) &&
+           (d->b_kmajor || d->N >= 8);
+  };
+  const bool together = g_gemm_path != 0 && g_gemm_pair != 0 && fast(d0) && fast(d1) && d0->a_kmajor == d1->a_kmajor &&
+                        d0->b_kmajor == d1->b_kmajor && d0->c_dtype == d1->c_dtype;
+  if (!together) {
+    rc = pg_gemm(d0, stream);
+    return rc != PG_OK ? rc : pg_gemm(d1, stream);
+  }
+  a.gx0 = (d0->N + BN - 1) / BN;
+  a.gx1 = (d1->N + BN - 1) / BN;
+  a.nb0 = a.gx0 * ((d0->M + BM - 1) / BM);
+  const int blocks = a.nb0 + a.gx1 * ((d1->M + BM - 1) / BM);
   hipStream_t st = (hipStream_t)stream;
-  ProfEntry* pe = nullptr;
-  if (g_prof.every > 0) {
-    ++g_prof.launches;
-    if (++g_prof.counter % g_prof.every == 0) {
-      ProfEntry e;
-      if (hipEventCreate(&e.a) == hipSuccess && hipEventCreate(&e.b) == hipSuccess) {
-        e.variant = (d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0);
-        e.flops = 2.0 * d->M * d->N * (double)d->K * d->batch;
-        g_prof.entries.push_back(e);
-        pe = &g_prof.entries.back();
-        hipEventRecord(pe->a, st);
-      }
-    }
-  }
-  int rc = PG_ERR_ARG;
-  const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
-                    (d->b_kmajor || d->N >= 8);
-  const long blocks128 = (long)grid.x * grid.y * grid.z;
-  if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
-    if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
-    else rc = launch_glds_n64<bf16_t>(d, a, st);
-  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide == 1 && d->N >= 2048 &&
-                      (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 160))) {
-    if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
-    else rc = launch_glds256<bf16_t>(d, a, st);
-  } else if (fast) {
-    const long blocks = blocks128;
-    const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
-    if (g_gemm_path == 5) {
-      if (d->c_dtype == PG_F32) rc = launch_glds<float, 5>(d, a, grid, st);
-      else rc = launch_glds<bf16_t, 5>(d, a, grid, st);
-    } else if (deep) {
-      if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);
-      else rc = launch_glds<bf16_t, 4>(d, a, grid, st);
-    } else {
-      if (d->c_dtype == PG_F32) rc = launch_glds<float, 2>(d, a, grid, st);
-      else rc = launch_glds<bf16_t, 2>(d, a, grid, st);
-    }
-  } else if (d->dtype == PG_BF16) {
-    if (d->c_dtype == PG_F32) rc = launch_layout<bf16_t, float>(d, a, grid, st);
-    else rc = launch_layout<bf16_t, bf16_t>(d, a, grid, st);
-  } else if (d->dtype == PG_F32) {
-    rc = launch_layout<float, float>(d, a, grid, st);
-  }
+  ProfEntry* pe = prof_begin(8 + (d0->c_dtype == PG_F32 ? 4 : 0) + (d0->a_kmajor ? 2 : 0) + (d0->b_kmajor ? 1 : 0),
+                             2.0 * d0->M * d0->N * (double)d0->K + 2.0 * d1->M * d1->N * (double)d1->K, st);
+  const int kmin = d0->K < d1->K ? d0->K : d1->K;
+  const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && kmin >= 4 * GBK);
+  if (deep) rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 4>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 4>(d0, a, blocks, st);
+  else rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 2>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 2>(d0, a, blocks, st);
   if (pe) hipEventRecord(pe->b, st);
   return rc;
 }

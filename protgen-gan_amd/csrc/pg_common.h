@@ -88,6 +88,23 @@ template <> struct VecIO<float, 4> {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
   }
 };
+template <> struct VecIO<bf16_t, 8> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* o) {
+    uint4 v;
+    v.x = (uint32_t)f32_to_bf16_bits(o[0]) | ((uint32_t)f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16_bits(o[2]) | ((uint32_t)f32_to_bf16_bits(o[3]) << 16);
+    v.z = (uint32_t)f32_to_bf16_bits(o[4]) | ((uint32_t)f32_to_bf16_bits(o[5]) << 16);
+    v.w = (uint32_t)f32_to_bf16_bits(o[6]) | ((uint32_t)f32_to_bf16_bits(o[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
 template <> struct VecIO<bf16_t, 4> {
   static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
     uint2 v = *reinterpret_cast<const uint2*>(p);

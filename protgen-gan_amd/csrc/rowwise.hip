@@ -278,6 +278,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, l
   if (rg == 0 && n < N) atomicAdd(db + n, red[c] + red[64 + c] + red[128 + c] + red[192 + c]);
 }
 
+// Vector form (16-byte-aligned rows, N a multiple of the 16-byte element count): a lane owns E
+// consecutive columns and reads them as one 16-byte load per row, so a wave covers 1 KiB of a
+// row; grid (ceil(N / (64 E)), row_chunks).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ dY, long ld, int rows, int N,
+                                                          float* __restrict__ db, int rows_per_chunk) {
+  constexpr int E = 16 / sizeof(T);
+  __shared__ float red[3][64 * E];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 64 + lane) * E;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  if (n0 < N) {
+    const T* p = dY + n0;
+#pragma unroll 4
+    for (int r = r0 + w; r < r1; r += 4) {
+      float v[E];
+      VecIO<T, E>::load(p + (long)r * ld, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] += v[e];
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[w - 1][e * 64 + lane] = s[e];
+  }
+  __syncthreads();
+  if (w == 0 && n0 < N) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(db + n0 + e, s[e] + red[0][e * 64 + lane] + red[1][e * 64 + lane] + red[2][e * 64 + lane]);
+  }
+}
+
 // ------------------------------------------------------------------ softmax family
 // One wave per score row; the row (<= 64*MAXI columns) lives in registers.
 constexpr int MAXI = 16;
@@ -556,6 +592,19 @@ extern "C" int pg_gelu_bwd2(int dtype, const void* u, const void* udot, const vo
 extern "C" int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float* db, void* stream) {
   if (!dY || !db || rows <= 0 || N <= 0) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const int E = dtype == PG_F32 ? 4 : 8;
+  if (ld % E == 0 && N % E == 0 && ((uintptr_t)dY) % 16 == 0) {
+    // about four workgroups per CU in flight: 32 rows (8 per wave) per chunk unless that is too many chunks
+    const int gx = (N + 64 * E - 1) / (64 * E);
+    int rpc = 32;
+    while ((long)gx * ((rows + rpc - 1) / rpc) > 2048) rpc *= 2;
+    dim3 grid(gx, (rows + rpc - 1) / rpc);
+    if (dtype == PG_F32)
+      hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, (long)ld, rows, N, db, rpc);
+    else
+      hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, (long)ld, rows, N, db, rpc);
+    return check_launch();
+  }
   int chunks = (rows + 255) / 256;
   if (chunks > 64) chunks = 64;
   const int rpc = (rows + chunks - 1) / chunks;

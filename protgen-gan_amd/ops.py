@@ -36,6 +36,31 @@ def _need_cuda(*ts):
             raise ValueError("protgen-gan_amd kernels need tensors on a HIP device (there is no CPU path)")
 
 
+def _plain_desc(A, B, C_out, a_kmajor, b_kmajor, M, N, K, alpha, beta):
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    d.dtype, d.c_dtype = dt_code(A.dtype), dt_code(C_out.dtype)
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), C_out.stride(0)
+    d.batch, d.batch_inner = 1, 1
+    d.alpha, d.beta = alpha, beta
+    return d
+
+
+def gemm_pair(A0, B0, C0, A1, B1, C1, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0):
+    """Two 2-D GEMMs of the same layout in one launch (pg_gemm_pair); outputs must be given."""
+    _need_cuda(A0, B0)
+    descs = []
+    for A, B, Cm in ((A0, B0, C0), (A1, B1, C1)):
+        M, K = (A.shape if a_kmajor else (A.shape[1], A.shape[0]))
+        N, K2 = (B.shape if b_kmajor else (B.shape[1], B.shape[0]))
+        assert K == K2 and A.stride(1) == 1 and B.stride(1) == 1 and Cm.shape == (M, N)
+        descs.append(_plain_desc(A, B, Cm, a_kmajor, b_kmajor, M, N, K, alpha, beta))
+    check(lib.pg_gemm_pair(C.byref(descs[0]), C.byref(descs[1]), stream()), "pg_gemm_pair")
+    return C0, C1
+
+
 def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alpha=1.0, beta=0.0, bias=None,
          residual=None, act=PG_ACT_NONE, aux=None, aux2=None):
     """2-D GEMM.  A is [M,K] (a_kmajor) or [K,M]; B is [N,K] (b_kmajor) or [K,N]."""
@@ -47,14 +72,7 @@ def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alph
     out_dtype = out_dtype or A.dtype
     if C_out is None:
         C_out = torch.empty(M, N, dtype=out_dtype, device=A.device)
-    d = _lib.GemmDesc()
-    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
-    d.dtype, d.c_dtype = dt_code(A.dtype), dt_code(C_out.dtype)
-    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
-    d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb, d.ldc = A.stride(0), B.stride(0), C_out.stride(0)
-    d.batch, d.batch_inner = 1, 1
-    d.alpha, d.beta = alpha, beta
+    d = _plain_desc(A, B, C_out, a_kmajor, b_kmajor, M, N, K, alpha, beta)
     d.bias = ptr(bias)
     if residual is not None:
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)

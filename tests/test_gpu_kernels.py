@@ -175,6 +175,27 @@ def test_gemm_weight_gradient_shape(pg, dtype):
     close(out, dY.double().T @ X.double(), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [256, 328])
+def test_gemm_pair_weight_gradients(pg, dtype, T):
+    """pg_gemm_pair: two accumulating weight-gradient products (different output shapes) in one
+    launch equal two pg_gemm calls.  T = 256 takes the single-launch bf16 kernel, T = 328 (not a
+    whole number of k-tiles) and fp32 the two-launch fallback."""
+    g = torch.Generator().manual_seed(31)
+    dY0, X0 = rnd(T, 136, dtype=dtype, gen=g), rnd(T, 128, dtype=dtype, gen=g)
+    dY1, X1 = rnd(T, 392, dtype=dtype, gen=g), rnd(T, 200, dtype=dtype, gen=g)
+    C0, C1 = torch.randn(136, 128, generator=g), torch.randn(392, 200, generator=g)
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    c0, c1 = C0.clone().to(DEV), C1.clone().to(DEV)
+    pg.ops.gemm_pair(d(dY0), d(X0), c0, d(dY1), d(X1), c1, a_kmajor=False, b_kmajor=False, alpha=1.0, beta=1.0)
+    close(c0, C0.double() + dY0.double().T @ X0.double(), dtype)
+    close(c1, C1.double() + dY1.double().T @ X1.double(), dtype)
+    e0, e1 = C0.clone().to(DEV), C1.clone().to(DEV)
+    pg.ops.gemm(d(dY0), d(X0), e0, a_kmajor=False, b_kmajor=False, beta=1.0)
+    pg.ops.gemm(d(dY1), d(X1), e1, a_kmajor=False, b_kmajor=False, beta=1.0)
+    assert torch.equal(c0, e0) and torch.equal(c1, e1)
+
+
 def test_gemm_rejects_bad_arguments(pg):
     with pytest.raises(pg._lib.PgError):  # fp32 leading dimension not a multiple of 4 elements
         pg.ops.gemm(torch.zeros(64, 34, device=DEV), torch.zeros(64, 34, device=DEV))
@@ -240,6 +261,15 @@ def test_gelu_bwd2_and_colsum(pg, dtype):
     db = torch.ones(200, device=DEV)
     pg.ops.colsum_acc(d(dY), db)
     close(db, dY.double().sum(0) + 1, torch.float32, mult=20)
+    # a column count that is not a multiple of the 16-byte vector takes the scalar kernel
+    db = torch.ones(197, device=DEV)
+    pg.ops.colsum_acc(d(dY)[:, :197], db)
+    close(db, dY[:, :197].double().sum(0) + 1, torch.float32, mult=20)
+    # wide and tall: several column blocks and row chunks of the vector kernel
+    dY = rnd(4100, 1032, dtype=dtype, gen=g)
+    db = torch.zeros(1032, device=DEV)
+    pg.ops.colsum_acc(d(dY), db)
+    close(db, dY.double().sum(0), torch.float32, mult=200)
 
 
 # ----------------------------------------------------------------------------- softmax family
