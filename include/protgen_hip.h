@@ -107,7 +107,7 @@ int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void* stream);
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
-int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1) */
+int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1); key 6: fused attention kernels in the gradient-penalty passes (0/1) */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 
@@ -164,6 +164,22 @@ int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, v
  * second half is two GEMMs: dK = dS^T Q / 8, dV = P^T dO. */
 int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dq,
                         int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream);
+/* Gradient-penalty passes of one attention block over the stored probabilities P
+ * (the double backward torch.autograd.grad(..., create_graph=True) takes through
+ * eager_attention_forward, modeling_bert.py:111-136, for loss.py:33-48).  bf16 only, S <= 2048.
+ * pg_attention_jvp: tangent pass.  tqkv holds (dQ | dK | dV) in the layout of qkv; writes
+ *   dctx = dP V + P dV with dP = P (dS - rho), dS = (dQ K^T + Q dK^T)/8, and rho = rowsum(P dS)
+ *   ([B*heads][S], fp32) for the pass below.
+ * pg_attention_bwd2: score side of the second-order reverse pass.  gctx is the first-order
+ *   adjoint of ctx, ctxbar the second-order one; writes (bf16, [B*heads][S][pg_score_ld(S)])
+ *   Sbar = P (X + gamma (dS - rho) - c dS - e) and dP, where gamma = gctx V^T,
+ *   X = ctxbar V^T + gctx dV^T, c = <gctx, ctx>, e = <ctxbar, ctx> + <gctx, dctx> - rho c. */
+int pg_attention_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot, float* rho,
+                     int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out, void* stream);
+int pg_attention_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, const void* ctxdot,
+                      const void* gctx, const void* ctxbar, const float* rho, void* Sbar, void* Pdot, int B, int S, int heads,
+                      int64_t ld_qkv, int64_t ld_ctx, void* stream);
+
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */

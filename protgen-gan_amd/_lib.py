@@ -77,6 +77,8 @@ SIGNATURES = {
     "pg_attention_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
     "pg_attention_fwd_p": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
     "pg_attention_bwd_dq": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp]),
+    "pg_attention_jvp": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp]),
+    "pg_attention_bwd2": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
     "pg_score_ld": (i32, [i32]),
     "pg_softmax_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "pg_softmax_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp]),

@@ -643,6 +643,410 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
 }
 
+
+// ---- gradient-penalty passes over the stored probabilities ---------------------------------
+// Both kernels below keep the query-on-the-lane formulation: a score-shaped product X^T = T R^T
+// takes its A operand from a 64-key LDS tile T (K, dK, V or dV rows, k-major in the head
+// dimension) and its B operand from per-lane row fragments R[q][32kk + 8g .. +8] read once from
+// global memory; lane (q = lane & 15, g = lane >> 4) then holds keys 16 blk + 4g + e of query q.
+
+// Row fragments of one [T][ld] activation (head h): both 16-query groups, both k-steps.
+__device__ __forceinline__ void load_row_frags(const bf16_t* __restrict__ base, long ld, const int (&qrow)[2], int g,
+                                               bf16x8_t (&f)[2][2]) {
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 v = *reinterpret_cast<const uint4*>(base + (long)qrow[qg] * ld + kk * 32 + 8 * g);
+      f[qg][kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+// <a_q, b_q> over the 64 head-dim values of each of the lane's two query rows.
+__device__ __forceinline__ void row_dots(const bf16x8_t (&a)[2][2], const bf16x8_t (&b)[2][2], float (&out)[2]) {
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    float acc = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)a[qg][kk][e] * (float)b[qg][kk][e];
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    out[qg] = acc;
+  }
+}
+
+__device__ __forceinline__ void read_kmajor_frags(unsigned tile_addr, const unsigned (&koff)[2], u32x4 (&f)[4][2]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    f[0][kk] = rd128<0>(tile_addr + koff[kk]);
+    f[1][kk] = rd128<2048>(tile_addr + koff[kk]);
+    f[2][kk] = rd128<4096>(tile_addr + koff[kk]);
+    f[3][kk] = rd128<6144>(tile_addr + koff[kk]);
+  }
+}
+
+template <bool ZERO>
+__device__ __forceinline__ void score_product(const u32x4 (&tf)[4][2], const bf16x8_t (&rf)[2][2], f32x4 (&acc)[2][4]) {
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4 a = ZERO ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[qg][blk];
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, tf[blk][0]), rf[qg][0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, tf[blk][1]), rf[qg][1], a, 0, 0, 0);
+      acc[qg][blk] = a;
+    }
+}
+
+template <bool ZERO>
+__device__ __forceinline__ void score_product1(const u32x4 (&tf)[4][2], const bf16x8_t (&rf)[2], f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    f32x4 a = ZERO ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[blk];
+    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, tf[blk][0]), rf[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, tf[blk][1]), rf[1], a, 0, 0, 0);
+    acc[blk] = a;
+  }
+}
+
+// Tangent (forward-mode) pass of one attention head block, given P:
+//   dS = (dQ K^T + Q dK^T) / 8 ; rho_q = sum_k P dS ; dP = P (dS - rho)
+//   dctx = dP V + P dV = (P dS) V - rho ctx + P dV
+// One sweep over the keys; nothing score-shaped is written.  rho ([B*heads][S], fp32) is kept
+// for the second-order reverse pass, which recomputes dS from the same operands.
+__global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ tqkv,
+                                                           const bf16_t* __restrict__ P, const bf16_t* __restrict__ ctx,
+                                                           bf16_t* __restrict__ ctxdot, float* __restrict__ rho, int S, int ldS,
+                                                           int heads, long ld_qkv, long ld_ctx, long ld_out) {
+  __shared__ __align__(16) bf16_t smem[8 * TILE];  // [buffer][K | dK | V | dV]
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const long row0 = (long)b * S;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
+  const bf16_t* Qd = tqkv + row0 * ld_qkv + h * 64;
+  const int q0 = qt * QB + wid * 32;
+  int qrow[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    qrow[qg] = q < S ? q : S - 1;
+  }
+  bf16x8_t qf[2][2], qdf[2][2];
+  load_row_frags(Q, ld_qkv, qrow, g, qf);
+  load_row_frags(Qd, ld_qkv, qrow, g, qdf);
+
+  unsigned koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  unsigned voff[2][4];
+  {
+    const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int k = 4 * g + qq + 16 * hi;
+        const int c = 2 * d + (pp >> 1);
+        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+      }
+  }
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const int nt = (S + KT - 1) / KT;
+  const bf16_t* Pz = P + (long)bh * S * ldS;
+
+  f32x4 o[2][4];
+  float racc[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint2 pcur[2][4], pnext[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_tile(Q + H, ld_qkv, 0, S, smem, wid, lane);
+  stage_tile(Qd + H, ld_qkv, 0, S, smem + TILE, wid, lane);
+  stage_tile(Q + 2 * H, ld_qkv, 0, S, smem + 2 * TILE, wid, lane);
+  stage_tile(Qd + 2 * H, ld_qkv, 0, S, smem + 3 * TILE, wid, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+      bf16_t* nb = smem + ((t + 1) & 1) * 4 * TILE;
+      stage_tile(Q + H, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
+      stage_tile(Qd + H, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+      stage_tile(Q + 2 * H, ld_qkv, (t + 1) * KT, S, nb + 2 * TILE, wid, lane);
+      stage_tile(Qd + 2 * H, ld_qkv, (t + 1) * KT, S, nb + 3 * TILE, wid, lane);
+    }
+    const unsigned ka = smem_addr + (t & 1) * 8 * TILE;
+    const unsigned kda = ka + 2 * TILE, va = ka + 4 * TILE, vda = ka + 6 * TILE;
+    f32x4 ds[2][4];
+    {
+      u32x4 kf[4][2];
+      read_kmajor_frags(ka, koff, kf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product<true>(kf, qdf, ds);
+      __builtin_amdgcn_sched_barrier(0);
+      read_kmajor_frags(kda, koff, kf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product<false>(kf, qf, ds);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // V^T fragments in flight under the elementwise part
+    u32x2 vlo[2][4], vhi[2][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      vlo[0][d] = rdtr<0>(va + voff[0][d]);
+      vhi[0][d] = rdtr<0>(va + voff[1][d]);
+      vlo[1][d] = rdtr<4096>(va + voff[0][d]);
+      vhi[1][d] = rdtr<4096>(va + voff[1][d]);
+    }
+    bf16x8_t pdf[2][2], pf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const uint2 pr = pcur[qg][blk];
+        const float p0 = __uint_as_float(pr.x << 16), p1 = __uint_as_float(pr.x & 0xffff0000u);
+        const float p2 = __uint_as_float(pr.y << 16), p3 = __uint_as_float(pr.y & 0xffff0000u);
+        const float pd[4] = {p0 * ds[qg][blk][0] * 0.125f, p1 * ds[qg][blk][1] * 0.125f, p2 * ds[qg][blk][2] * 0.125f,
+                             p3 * ds[qg][blk][3] * 0.125f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          racc[qg] += pd[e];
+          ds[qg][blk][e] = pd[e];
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p8[e] = (__bf16)ds[qg][2 * s2][e];
+          p8[4 + e] = (__bf16)ds[qg][2 * s2 + 1][e];
+        }
+        pdf[qg][s2] = p8;
+        const u32x4 raw = (u32x4){pcur[qg][2 * s2].x, pcur[qg][2 * s2].y, pcur[qg][2 * s2 + 1].x, pcur[qg][2 * s2 + 1].y};
+        pf[qg][s2] = __builtin_bit_cast(bf16x8_t, raw);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 vv = (u32x4){vlo[s2][d][0], vlo[s2][d][1], vhi[s2][d][0], vhi[s2][d][1]};
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg)
+          o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pdf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {  // dV^T into the same registers
+      vlo[0][d] = rdtr<0>(vda + voff[0][d]);
+      vhi[0][d] = rdtr<0>(vda + voff[1][d]);
+      vlo[1][d] = rdtr<4096>(vda + voff[0][d]);
+      vhi[1][d] = rdtr<4096>(vda + voff[1][d]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 ww = (u32x4){vlo[s2][d][0], vlo[s2][d][1], vhi[s2][d][0], vhi[s2][d][1]};
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg)
+          o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ww), pf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    float rq = racc[qg];
+    rq += __shfl_xor(rq, 16, 64);
+    rq += __shfl_xor(rq, 32, 64);
+    const int q = q0 + qg * 16 + r;
+    if (q >= S) continue;
+    if (g == 0) rho[(long)bh * S + q] = rq;
+    const bf16_t* cs = ctx + (row0 + q) * ld_ctx + h * 64 + 4 * g;
+    bf16_t* dst = ctxdot + (row0 + q) * ld_out + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float c4[4];
+      VecIO<bf16_t, 4>::load(cs + d * 16, c4);
+      float v[4] = {o[qg][d][0] - rq * c4[0], o[qg][d][1] - rq * c4[1], o[qg][d][2] - rq * c4[2], o[qg][d][3] - rq * c4[3]};
+      VecIO<bf16_t, 4>::store(dst + d * 16, v);
+    }
+  }
+}
+
+// Score side of the second-order reverse pass of one attention head block.  With P, the
+// tangent dS (recomputed), gamma = gctx V^T, X = ctxbar V^T + gctx dV^T and the row scalars
+//   rho = sum P dS (from the tangent pass), c = <gctx, ctx>, e = <ctxbar, ctx> + <gctx, dctx> - rho c
+// it writes   Sbar = P (X + gamma (dS - rho) - c dS - e)   and   dP = P (dS - rho)
+// (both bf16, [B*heads][S][ldS]); the key-side contractions over them are plain GEMMs.
+__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ tqkv,
+                                                            const bf16_t* __restrict__ P, const bf16_t* __restrict__ ctx,
+                                                            const bf16_t* __restrict__ ctxdot, const bf16_t* __restrict__ gctx,
+                                                            const bf16_t* __restrict__ ctxbar, const float* __restrict__ rho,
+                                                            bf16_t* __restrict__ Sbar, bf16_t* __restrict__ Pdot, int S, int ldS,
+                                                            int heads, long ld_qkv, long ld_ctx) {
+  __shared__ __align__(16) bf16_t smem[8 * TILE];  // [buffer][K | dK | V | dV]
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const long row0 = (long)b * S;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
+  const bf16_t* Qd = tqkv + row0 * ld_qkv + h * 64;
+  const int q0 = qt * QB + wid * 32;
+  int qrow[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    qrow[qg] = q < S ? q : S - 1;
+  }
+  bf16x8_t qf[2][2], qdf[2][2], gf[2][2], cbf[2][2];
+  load_row_frags(Q, ld_qkv, qrow, g, qf);
+  load_row_frags(Qd, ld_qkv, qrow, g, qdf);
+  load_row_frags(gctx + row0 * ld_ctx + h * 64, ld_ctx, qrow, g, gf);
+  load_row_frags(ctxbar + row0 * ld_ctx + h * 64, ld_ctx, qrow, g, cbf);
+  float rq[2], cq[2], eq[2];
+  {
+    bf16x8_t cf[2][2], cdf[2][2];
+    load_row_frags(ctx + row0 * ld_ctx + h * 64, ld_ctx, qrow, g, cf);
+    load_row_frags(ctxdot + row0 * ld_ctx + h * 64, ld_ctx, qrow, g, cdf);
+    float e1[2], e2[2];
+    row_dots(gf, cf, cq);
+    row_dots(cbf, cf, e1);
+    row_dots(gf, cdf, e2);
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      rq[qg] = rho[(long)bh * S + qrow[qg]];
+      eq[qg] = e1[qg] + e2[qg] - rq[qg] * cq[qg];
+    }
+  }
+
+  unsigned koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const int nt = (S + KT - 1) / KT;
+  const bf16_t* Pz = P + (long)bh * S * ldS;
+  bf16_t* Sbz = Sbar + (long)bh * S * ldS;
+  bf16_t* Pdz = Pdot + (long)bh * S * ldS;
+
+  uint2 pcur[2][4], pnext[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_tile(Q + H, ld_qkv, 0, S, smem, wid, lane);
+  stage_tile(Qd + H, ld_qkv, 0, S, smem + TILE, wid, lane);
+  stage_tile(Q + 2 * H, ld_qkv, 0, S, smem + 2 * TILE, wid, lane);
+  stage_tile(Qd + 2 * H, ld_qkv, 0, S, smem + 3 * TILE, wid, lane);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+      bf16_t* nb = smem + ((t + 1) & 1) * 4 * TILE;
+      stage_tile(Q + H, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
+      stage_tile(Qd + H, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+      stage_tile(Q + 2 * H, ld_qkv, (t + 1) * KT, S, nb + 2 * TILE, wid, lane);
+      stage_tile(Qd + 2 * H, ld_qkv, (t + 1) * KT, S, nb + 3 * TILE, wid, lane);
+    }
+    const unsigned ka = smem_addr + (t & 1) * 8 * TILE;
+    const unsigned kda = ka + 2 * TILE, va = ka + 4 * TILE, vda = ka + 6 * TILE;
+    // one 16-query group at a time: three score-shaped accumulators of one group are live, the
+    // tile fragments are re-read for the second group (the kernel is bound by its stores)
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      f32x4 ds[4], gm[4], xx[4];
+      u32x4 tf[4][2];
+      read_kmajor_frags(ka, koff, tf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product1<true>(tf, qdf[qg], ds);
+      __builtin_amdgcn_sched_barrier(0);
+      read_kmajor_frags(kda, koff, tf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product1<false>(tf, qf[qg], ds);
+      __builtin_amdgcn_sched_barrier(0);
+      read_kmajor_frags(va, koff, tf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product1<true>(tf, gf[qg], gm);
+      score_product1<true>(tf, cbf[qg], xx);
+      __builtin_amdgcn_sched_barrier(0);
+      read_kmajor_frags(vda, koff, tf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_product1<false>(tf, gf[qg], xx);
+      __builtin_amdgcn_sched_barrier(0);
+      const int q = q0 + qg * 16 + r;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const uint2 pr = pcur[qg][blk];
+        const float pv[4] = {__uint_as_float(pr.x << 16), __uint_as_float(pr.x & 0xffff0000u), __uint_as_float(pr.y << 16),
+                             __uint_as_float(pr.y & 0xffff0000u)};
+        float sb[4], pd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = ds[blk][e] * 0.125f;
+          const float pbar = xx[blk][e] + gm[blk][e] * (d - rq[qg]) - cq[qg] * d;
+          sb[e] = pv[e] * (pbar - eq[qg]);
+          pd[e] = pv[e] * (d - rq[qg]);
+        }
+        if (q < S) {
+          const long o = (long)q * ldS + t * KT + blk * 16 + 4 * g;
+          VecIO<bf16_t, 4>::store(Sbz + o, sb);
+          VecIO<bf16_t, 4>::store(Pdz + o, pd);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
@@ -679,5 +1083,37 @@ extern "C" int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, co
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
                      (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, pg_score_ld(S), heads, (long)ld_qkv,
                      (long)ld_ctx, (long)ld_dq);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot,
+                                float* rho, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out,
+                                void* stream) {
+  if (!qkv || !tqkv || !P || !ctx || !ctxdot || !rho || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 4) || (ld_out % 4)) return PG_ERR_ALIGN;
+  if ((((uintptr_t)qkv) | ((uintptr_t)tqkv)) & 15) return PG_ERR_ALIGN;
+  if ((((uintptr_t)P) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot)) & 7) return PG_ERR_ALIGN;
+  dim3 grid((S + QB - 1) / QB, B * heads);
+  hipLaunchKernelGGL(attn_jvp_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
+                     (const bf16_t*)P, (const bf16_t*)ctx, (bf16_t*)ctxdot, rho, S, pg_score_ld(S), heads, (long)ld_qkv,
+                     (long)ld_ctx, (long)ld_out);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
+                                 const void* ctxdot, const void* gctx, const void* ctxbar, const float* rho, void* Sbar,
+                                 void* Pdot, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!qkv || !tqkv || !P || !ctx || !ctxdot || !gctx || !ctxbar || !rho || !Sbar || !Pdot) return PG_ERR_ARG;
+  if (B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 8)) return PG_ERR_ALIGN;
+  if ((((uintptr_t)qkv) | ((uintptr_t)tqkv) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot) | ((uintptr_t)gctx) | ((uintptr_t)ctxbar)) & 15)
+    return PG_ERR_ALIGN;
+  if ((((uintptr_t)P) | ((uintptr_t)Sbar) | ((uintptr_t)Pdot)) & 7) return PG_ERR_ALIGN;
+  dim3 grid((S + QB - 1) / QB, B * heads);
+  hipLaunchKernelGGL(attn_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
+                     (const bf16_t*)P, (const bf16_t*)ctx, (const bf16_t*)ctxdot, (const bf16_t*)gctx, (const bf16_t*)ctxbar, rho,
+                     (bf16_t*)Sbar, (bf16_t*)Pdot, S, pg_score_ld(S), heads, (long)ld_qkv, (long)ld_ctx);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }

@@ -13,6 +13,8 @@
 #include "pg_common.h"
 #include "protgen_hip.h"
 
+extern int pg_internal_fused_gp;  // pg_tune key 6 (defined beside pg_tune)
+
 namespace {
 
 struct Dims {
@@ -161,6 +163,10 @@ struct G {
     return pg_gemm(&d, st);
   }
 };
+
+// The tangent and second-order passes must agree on this: with the fused kernels the score slot
+// of the tangent stash holds rho ([B*heads][S] fp32), otherwise the tangent scores.
+inline bool fused_gp_attention(int dtype, int S) { return pg_internal_fused_gp && dtype == PG_BF16 && S <= 2048; }
 
 inline char* off(char* p, long elems, int es) { return p + elems * es; }
 inline const char* off(const char* p, long elems, int es) { return p + elems * es; }
@@ -452,17 +458,22 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
     const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
     const Slots t = layer_slots((char*)tan_stash, sl, d, l);
     CK(g.run(t.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, t.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f));
-    // Sdot = (Qdot K^T + Q Kdot^T)/8
-    CK(g.bat(d, t.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-             0.125f, 0.f));
-    CK(g.bat(d, s.qkv, true, 3 * H, false, off(t.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-             0.125f, 1.f));
-    CK(pg_softmax_jvp(dtype, w.sc0, s.ss, t.ss, w.ss0, (int)d.Z, S, st));
-    // ctxdot = Pdot V + P Vdot
-    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
-             0.f));
-    CK(g.bat(d, s.ss, true, d.ldS, true, off(t.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
-             1.f));
+    if (fused_gp_attention(dtype, S)) {
+      // one sweep; the score slot of the tangent stash keeps only rho = rowsum(P Sdot)
+      CK(pg_attention_jvp(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, (float*)t.ss, B, S, d.nh, 3 * H, H, H, st));
+    } else {
+      // Sdot = (Qdot K^T + Q Kdot^T)/8
+      CK(g.bat(d, t.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+               0.125f, 0.f));
+      CK(g.bat(d, s.qkv, true, 3 * H, false, off(t.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
+               0.125f, 1.f));
+      CK(pg_softmax_jvp(dtype, w.sc0, s.ss, t.ss, w.ss0, (int)d.Z, S, st));
+      // ctxdot = Pdot V + P Vdot
+      CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
+               0.f));
+      CK(g.bat(d, s.ss, true, d.ldS, true, off(t.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
+               1.f));
+    }
     CK(g.run(t.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, t.a, dtype, H, T, H, H, 1.f, 0.f, nullptr, t.x, H));
     CK(pg_layernorm_jvp(dtype, s.a, t.a, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, t.h, T, H, st));
     CK(g.run(t.h, true, H, pv.w(pv.lo(l, PG_L_W1)), true, H, t.gu, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
@@ -532,10 +543,15 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     // attention second order
     const char* v = off(s.qkv, 2 * H, es);
     const char* vdot = off(t.qkv, 2 * H, es);
-    CK(g.bat(d, a.ctx, true, H, false, v, true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // gP
-    CK(g.bat(d, w.ctx, true, H, false, v, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // X
-    CK(g.bat(d, a.ctx, true, H, false, vdot, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 1.f));
-    CK(pg_softmax_bwd2(dtype, s.ss, t.ss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)d.Z, S, st));
+    if (fused_gp_attention(dtype, S)) {
+      CK(pg_attention_bwd2(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, a.ctx, w.ctx, (const float*)t.ss, w.ss0 /*Sbar*/,
+                           w.ss1 /*Pdot*/, B, S, d.nh, 3 * H, H, st));
+    } else {
+      CK(g.bat(d, a.ctx, true, H, false, v, true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // gP
+      CK(g.bat(d, w.ctx, true, H, false, v, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // X
+      CK(g.bat(d, a.ctx, true, H, false, vdot, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 1.f));
+      CK(pg_softmax_bwd2(dtype, s.ss, t.ss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)d.Z, S, st));
+    }
     // qbar = (Sbar K + gS Kdot)/8
     CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, w.qkv, dtype, 3 * H, false, S, 64, S,
              0.125f, 0.f));

@@ -1112,6 +1112,8 @@ int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring dep
 
 }  // namespace
 
+int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
+
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
@@ -1119,6 +1121,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 3) { g_gemm_dbg = value; return PG_OK; }
   if (key == 4) { g_gemm_ep8 = value; return PG_OK; }
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
+  if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 

@@ -220,6 +220,38 @@ def attention_fwd(qkv, mask, B, S, heads):
     return ctx
 
 
+def attention_bwd_dq(qkv, P, ctx, dctx, B, S, heads):
+    """First half of the attention backward over stored P: returns (dS [B*heads,S,ld], dq [B*S,H])."""
+    H = heads * 64
+    dS = torch.zeros(B * heads, S, score_ld(S), dtype=qkv.dtype, device=qkv.device)
+    dq = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
+    check(lib.pg_attention_bwd_dq(dt_code(qkv.dtype), qkv.data_ptr(), P.data_ptr(), ctx.data_ptr(), dctx.data_ptr(),
+                                  dS.data_ptr(), dq.data_ptr(), B, S, heads, qkv.stride(0), ctx.stride(0), dq.stride(0),
+                                  stream()), "pg_attention_bwd_dq")
+    return dS, dq
+
+
+def attention_jvp(qkv, tqkv, P, ctx, B, S, heads):
+    """Tangent pass over stored P: returns (dctx [B*S,H], rho [B*heads,S] fp32)."""
+    H = heads * 64
+    ctxdot = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
+    rho = torch.empty(B * heads, S, dtype=torch.float32, device=qkv.device)
+    check(lib.pg_attention_jvp(dt_code(qkv.dtype), qkv.data_ptr(), tqkv.data_ptr(), P.data_ptr(), ctx.data_ptr(),
+                               ctxdot.data_ptr(), rho.data_ptr(), B, S, heads, qkv.stride(0), ctx.stride(0),
+                               ctxdot.stride(0), stream()), "pg_attention_jvp")
+    return ctxdot, rho
+
+
+def attention_bwd2(qkv, tqkv, P, ctx, ctxdot, gctx, ctxbar, rho, B, S, heads):
+    """Score side of the second-order reverse pass: returns (Sbar, dP), both [B*heads,S,ld]."""
+    Sbar = torch.zeros(B * heads, S, score_ld(S), dtype=qkv.dtype, device=qkv.device)
+    Pdot = torch.zeros_like(Sbar)
+    check(lib.pg_attention_bwd2(dt_code(qkv.dtype), qkv.data_ptr(), tqkv.data_ptr(), P.data_ptr(), ctx.data_ptr(),
+                                ctxdot.data_ptr(), gctx.data_ptr(), ctxbar.data_ptr(), rho.data_ptr(), Sbar.data_ptr(),
+                                Pdot.data_ptr(), B, S, heads, qkv.stride(0), ctx.stride(0), stream()), "pg_attention_bwd2")
+    return Sbar, Pdot
+
+
 def attention_fwd_p(qkv, mask, B, S, heads):
     """As attention_fwd, also returning P [B*heads, S, score_ld(S)]."""
     H = heads * 64

@@ -342,6 +342,55 @@ def test_fused_attention_forward(pg, S):
             assert float(P[:, :, S:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("S", [40, 200, 512])
+def test_fused_attention_training_passes(pg, S):
+    """The three kernels that work on the stored probabilities P, against fp64 on the same
+    bf16-rounded operands (P as the forward kernel stored it):
+      first-order backward   dS = P (dP - delta), dq = dS K / 8
+      tangent pass           dctx = Pdot V + P dV, rho = rowsum(P dS)
+      second-order scores    Sbar, Pdot of the softmax double backward (tests/kernel_specs.py)."""
+    g = torch.Generator().manual_seed(90 + S)
+    B, nh = 2, 2
+    H, Z = nh * 64, B * nh
+    bf = torch.bfloat16
+    qkv, tqkv = rnd(B * S, 3 * H, dtype=bf, gen=g), rnd(B * S, 3 * H, dtype=bf, gen=g)
+    gctx, ctxbar = rnd(B * S, H, dtype=bf, gen=g), rnd(B * S, H, dtype=bf, gen=g)
+    mask = torch.ones(B, S)
+    mask[0, S - 7:] = 0
+    mask[1, 3] = 0
+    d = lambda t: t.to(bf).to(DEV)  # noqa: E731
+    ctx_d, P_d = pg.ops.attention_fwd_p(d(qkv), mask.to(DEV), B, S, nh)
+    heads = lambda t, i=0: t[:, i * H:(i + 1) * H].double().view(B, S, nh, 64).transpose(1, 2)  # noqa: E731
+    q, k, v = (heads(qkv, i) for i in range(3))
+    qd, kd, vd = (heads(tqkv, i) for i in range(3))
+    P = P_d[:, :, :S].double().cpu().view(B, nh, S, S)
+    ctx = ctx_d.double().cpu()
+    flat = lambda t: t.transpose(1, 2).reshape(B * S, H)  # noqa: E731
+    # first-order backward
+    dP = heads(gctx) @ v.transpose(2, 3)
+    delta = (gctx.double() * ctx).view(B, S, nh, 64).sum(-1).transpose(1, 2).unsqueeze(-1)
+    dS_ref = P * (dP - delta)
+    dS, dq = pg.ops.attention_bwd_dq(d(qkv), P_d, ctx_d, d(gctx), B, S, nh)
+    close(dS[:, :, :S], dS_ref.reshape(Z, S, S), bf)
+    close(dq, flat(dS_ref @ k) * 0.125, bf)
+    # tangent pass
+    Sd = (qd @ k.transpose(2, 3) + q @ kd.transpose(2, 3)) * 0.125
+    rho_ref = (P * Sd).sum(-1, keepdim=True)
+    Pd_ref = P * (Sd - rho_ref)
+    ctxdot, rho = pg.ops.attention_jvp(d(qkv), d(tqkv), P_d, ctx_d, B, S, nh)
+    close(rho, rho_ref.reshape(Z, S), bf)
+    close(ctxdot, flat(Pd_ref @ v + P @ vd), bf)
+    # second-order scores (with the device's own dctx and rho, as the engine chains them)
+    cd = ctxdot.double().cpu()
+    gam = heads(gctx) @ v.transpose(2, 3)
+    X = heads(ctxbar) @ v.transpose(2, 3) + heads(gctx) @ vd.transpose(2, 3)
+    Sbar_ref, Pd2_ref = K.softmax_bwd2(P, Sd, gam, X)
+    Sbar, Pd = pg.ops.attention_bwd2(d(qkv), d(tqkv), P_d, ctx_d, ctxdot, d(gctx), d(ctxbar), rho, B, S, nh)
+    close(Pd[:, :, :S], Pd2_ref.reshape(Z, S, S), bf)
+    close(Sbar[:, :, :S], Sbar_ref.reshape(Z, S, S), bf, mult=2)
+    del cd
+
+
 # ----------------------------------------------------------------------------- sampler
 def test_mlm_decode_sample_commit(pg):
     g = torch.Generator().manual_seed(8)
