@@ -124,21 +124,22 @@ int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* 
 /* y = LayerNorm(x) (modeling_bert.py:289-293,347-351; residual is added by the GEMM epilogue). */
 int pg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                  int rows, int H, void* stream);
-/* dx = LN'(x)^T dy ; dgamma += sum dy*xhat ; dbeta += sum dy (dgamma/dbeta may be NULL).
- * `partial` is fp32 scratch of 2*H*pg_ln_partial_rows(rows) floats.                   */
+/* dx = LN'(x)^T dy ; dgamma += sum dy*xhat ; dbeta += sum dy ; dxsum += column sums of dx, which
+ * is the bias gradient of the Linear whose output (plus residual) this LayerNorm normalises
+ * (any of the three may be NULL).  `partial` is fp32 scratch of 3*H*pg_ln_partial_rows(rows) floats. */
 int pg_ln_partial_rows(int rows);
 int pg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
-                     float* dgamma, float* dbeta, float* partial, int rows, int H, void* stream);
+                     float* dgamma, float* dbeta, float* dxsum, float* partial, int rows, int H, void* stream);
 /* Tangent (JVP): ydot = gamma * rstd * Proj(xdot). */
 int pg_layernorm_jvp(int dtype, const void* x, const void* xdot, const float* gamma, float eps, void* ydot,
                      int rows, int H, void* stream);
 /* Second-order reverse of the (primal, tangent) pair used by the gradient penalty:
  *   xbar = LN'(x)^T ybar + d/dx <gy, LN_jvp(x; xdot)>,
- *   dgamma += sum ybar*xhat + sum gy*rstd*Proj(xdot), dbeta += sum ybar.
+ *   dgamma += sum ybar*xhat + sum gy*rstd*Proj(xdot), dbeta += sum ybar, dxsum += column sums of xbar.
  * ybar may be NULL (treated as zero).                                                    */
 int pg_layernorm_bwd2(int dtype, const void* x, const void* xdot, const void* gy, const void* ybar,
-                      const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* partial,
-                      int rows, int H, void* stream);
+                      const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* dxsum,
+                      float* partial, int rows, int H, void* stream);
 /* ubar = gelu'(u)*gubar + gelu''(u)*udot*ggu  (GP second-order reverse of BertIntermediate's GELU). */
 int pg_gelu_bwd2(int dtype, const void* u, const void* udot, const void* ggu, const void* gubar, void* ubar,
                  int64_t n, void* stream);

@@ -69,9 +69,9 @@ SIGNATURES = {
     "pg_embed_ln2": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
     "pg_layernorm": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp]),
     "pg_ln_partial_rows": (i32, [i32]),
-    "pg_layernorm_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "pg_layernorm_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "pg_layernorm_jvp": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp]),
-    "pg_layernorm_bwd2": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "pg_layernorm_bwd2": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "pg_gelu_bwd2": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "pg_colsum_acc": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "pg_attention_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, i64, vp]),

@@ -484,10 +484,10 @@ class ProtBertForMaskedLM(nn.Module):
         H = self.config.hidden_size
         dt = ops.dt_code(self.compute_dtype)
         dsum = torch.empty_like(esum)
-        part = torch.empty(2 * H * lib.pg_ln_partial_rows(B * S), dtype=torch.float32, device=ids.device)
+        part = torch.empty(3 * H * lib.pg_ln_partial_rows(B * S), dtype=torch.float32, device=ids.device)
         check(lib.pg_layernorm_bwd(dt, esum.data_ptr(), dout.data_ptr(), self._gp(_lib.P_EMB_LN_G),
                                    self.config.layer_norm_eps, dsum.data_ptr(), self._gg(_lib.P_EMB_LN_G),
-                                   self._gg(_lib.P_EMB_LN_B), part.data_ptr(), B * S, H, ops.stream()), "pg_layernorm_bwd")
+                                   self._gg(_lib.P_EMB_LN_B), None, part.data_ptr(), B * S, H, ops.stream()), "pg_layernorm_bwd")
         check(lib.pg_embed_scatter(dt, dsum.data_ptr(), ids.data_ptr(), self._gg(_lib.P_WORD_EMB), self._gg(_lib.P_POS_EMB),
                                    self._gg(_lib.P_TYPE_EMB), B, S, H, ops.stream()), "pg_embed_scatter")
 

@@ -86,7 +86,7 @@ Workspace ws_layout(const Dims& d, char* base) {
   w.f = take(d.T * d.H * d.es);
   w.x0 = take(d.T * d.H * d.es);
   w.x1 = take(d.T * d.H * d.es);
-  w.ln_partial = (float*)take(2L * d.H * 1024 * 4);
+  w.ln_partial = (float*)take(3L * d.H * 1024 * 4);
   w.mlm_tmp = nullptr;
   w.total_bytes = o;
   return w;
@@ -381,13 +381,11 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     }
     if (l == 0 && dx_out && !save) a.x = (char*)dx_out;
     // LN2
+    // (the column sums of a LayerNorm backward's output are the bias gradient of the Linear before it)
     CK(pg_layernorm_bwd(dtype, s.f, dy, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, a.f,
                         grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
-                        w.ln_partial, T, H, st));
-    if (grads) {
-      CK(g.run(a.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
-      CK(pg_colsum_acc(dtype, a.f, H, T, H, pv.g(pv.lo(l, PG_L_B2)), st));
-    }
+                        grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
+    if (grads) CK(g.run(a.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
     // d gu = df W2 ; du = dgu * gelu'(u)
     if (save) {
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.gu, dtype, I, T, I, H, 1.f, 0.f));
@@ -405,8 +403,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     // LN1
     CK(pg_layernorm_bwd(dtype, s.a, a.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, a.a,
                         grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
-                        w.ln_partial, T, H, st));
-    if (grads) CK(pg_colsum_acc(dtype, a.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));
+                        grads ? pv.g(pv.lo(l, PG_L_BO)) : nullptr, w.ln_partial, T, H, st));
     // dctx = da Wo   (dWo = da^T ctx waits for dWqkv below: 64 + 192 tiles fill the chip together)
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
@@ -517,11 +514,10 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     // LN2: fbar
     CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, w.f,
                          grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
-                         w.ln_partial, T, H, st));
+                         grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
     if (grads) {
       CK(g.run(w.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
       CK(g.run(a.f, false, H, t.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
-      CK(pg_colsum_acc(dtype, w.f, H, T, H, pv.g(pv.lo(l, PG_L_B2)), st));
     }
     // gubar = fbar W2 ; ubar = gelu'(u) gubar + gelu''(u) udot ggu
     CK(g.run(w.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
@@ -536,8 +532,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     // LN1: abar
     CK(pg_layernorm_bwd2(dtype, s.a, t.a, a.h, w.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, w.a,
                          grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
-                         w.ln_partial, T, H, st));
-    if (grads) CK(pg_colsum_acc(dtype, w.a, H, T, H, pv.g(pv.lo(l, PG_L_BO)), st));  // the Wo products pair with the QKV ones below
+                         grads ? pv.g(pv.lo(l, PG_L_BO)) : nullptr, w.ln_partial, T, H, st));  // (the Wo products pair with the QKV ones below)
     // ctxbar = abar Wo
     CK(g.run(w.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention second order

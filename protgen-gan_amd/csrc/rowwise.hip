@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void ln_jvp_kernel(const T* __restrict__ xin, 
 
 // ------------------------------------------------------------------ LN backward (first and second order)
 // Each wave walks rows wave_id, wave_id + n_waves, ... and keeps its dgamma/dbeta partial
-// sums in registers; partials go to `partial[wave][2][H]` and are reduced by
+// sums (and the column sums of its output rows: the bias gradient of the Linear that feeds
+// this LayerNorm) in registers; partials go to `partial[wave][3][H]` and are reduced by
 // ln_param_reduce_kernel.
 template <typename T, int VW, int NCH, bool SECOND>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, const T* __restrict__ xdot,
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, 
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (wave >= n_waves) return;
-  float g[N], dg[N], db[N];
+  float g[N], dg[N], db[N], dxs[N];
   row_load<float, VW, NCH>(gamma, lane, g);
 #pragma unroll
-  for (int i = 0; i < N; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  for (int i = 0; i < N; ++i) { dg[i] = 0.f; db[i] = 0.f; dxs[i] = 0.f; }
   const float invH = 1.0f / (float)H;
   for (long row = wave; row < rows; row += n_waves) {
     float x[N], out[N];
@@ -207,34 +208,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, 
       }
     }
     row_store<T, VW, NCH>(xbar + row * H, lane, out);
+#pragma unroll
+    for (int i = 0; i < N; ++i) dxs[i] += out[i];
   }
   if (partial) {
-    float* pg = partial + (long)wave * 2 * H;
+    float* pg = partial + (long)wave * 3 * H;
     row_store<float, VW, NCH>(pg, lane, dg);
     row_store<float, VW, NCH>(pg + H, lane, db);
+    row_store<float, VW, NCH>(pg + 2 * H, lane, dxs);
   }
 }
 
-// grid (ceil(2H/64), row_chunks): thread (c = tid&63, rg = tid>>6) sums partial rows rg, rg+4, ...
+// grid (ceil(3H/64), row_chunks): thread (c = tid&63, rg = tid>>6) sums partial rows rg, rg+4, ...
 // of its chunk for column c; the four row groups combine through LDS; one atomic per column.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int n_waves, int H,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int rows_per_chunk) {
+                                                              float* __restrict__ dxsum, int rows_per_chunk) {
   __shared__ float red[256];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;  // column in [0, 2H)
+  const int c = blockIdx.x * 64 + cl;  // column in [0, 3H)
+  float* dst = c < H ? dgamma : (c < 2 * H ? dbeta : dxsum);
   const int r0 = blockIdx.y * rows_per_chunk;
   const int r1 = min(n_waves, r0 + rows_per_chunk);
   float s = 0.f;
-  if (c < 2 * H)
-    for (int w = r0 + rg; w < r1; w += 4) s += partial[(long)w * 2 * H + c];
+  if (c < 3 * H && dst)
+    for (int w = r0 + rg; w < r1; w += 4) s += partial[(long)w * 3 * H + c];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (rg == 0 && c < 2 * H) {
-    const float t = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
-    if (c < H) { if (dgamma) atomicAdd(dgamma + c, t); }
-    else { if (dbeta) atomicAdd(dbeta + c - H, t); }
-  }
+  if (rg == 0 && c < 3 * H && dst) atomicAdd(dst + c % H, red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl]);
 }
 
 // ------------------------------------------------------------------ GELU second-order reverse
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ d
   for (int e = 0; e < E; ++e) s[e] = 0.f;
   if (n0 < N) {
     const T* p = dY + n0;
-#pragma unroll 4
+#pragma unroll 8
     for (int r = r0 + w; r < r1; r += 4) {
       float v[E];
       VecIO<T, E>::load(p + (long)r * ld, v);
@@ -532,8 +533,9 @@ extern "C" int pg_layernorm_jvp(int dtype, const void* x, const void* xdot, cons
 namespace {
 template <bool SECOND>
 int ln_bwd_launch(int dtype, const void* x, const void* xdot, const void* gy, const void* ybar, const float* gamma,
-                  float eps, void* xbar, float* dgamma, float* dbeta, float* partial, int rows, int H, hipStream_t st) {
-  const bool want_params = dgamma || dbeta;
+                  float eps, void* xbar, float* dgamma, float* dbeta, float* dxsum, float* partial, int rows, int H,
+                  hipStream_t st) {
+  const bool want_params = dgamma || dbeta || dxsum;
   if (want_params && !partial) return PG_ERR_WORKSPACE;
   const int n_waves = pg_ln_partial_rows(rows);
   const int blocks = row_blocks(n_waves);
@@ -552,24 +554,24 @@ int ln_bwd_launch(int dtype, const void* x, const void* xdot, const void* gy, co
     int chunks = (n_waves + 63) / 64;
     if (chunks > 16) chunks = 16;
     const int rpc = (n_waves + chunks - 1) / chunks;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * H + 63) / 64, chunks), dim3(256), 0, st, partial, n_waves, H,
-                       dgamma, dbeta, rpc);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((3 * H + 63) / 64, chunks), dim3(256), 0, st, partial, n_waves, H,
+                       dgamma, dbeta, dxsum, rpc);
   }
   return check_launch();
 }
 }  // namespace
 
 extern "C" int pg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
-                                float* dgamma, float* dbeta, float* partial, int rows, int H, void* stream) {
+                                float* dgamma, float* dbeta, float* dxsum, float* partial, int rows, int H, void* stream) {
   if (!x || !dy || !gamma || !dx || rows <= 0) return PG_ERR_ARG;
-  return ln_bwd_launch<false>(dtype, x, nullptr, dy, nullptr, gamma, eps, dx, dgamma, dbeta, partial, rows, H,
+  return ln_bwd_launch<false>(dtype, x, nullptr, dy, nullptr, gamma, eps, dx, dgamma, dbeta, dxsum, partial, rows, H,
                               (hipStream_t)stream);
 }
 extern "C" int pg_layernorm_bwd2(int dtype, const void* x, const void* xdot, const void* gy, const void* ybar,
-                                 const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* partial,
-                                 int rows, int H, void* stream) {
+                                 const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* dxsum,
+                                 float* partial, int rows, int H, void* stream) {
   if (!x || !xdot || !gy || !gamma || !xbar || rows <= 0) return PG_ERR_ARG;
-  return ln_bwd_launch<true>(dtype, x, xdot, gy, ybar, gamma, eps, xbar, dgamma, dbeta, partial, rows, H,
+  return ln_bwd_launch<true>(dtype, x, xdot, gy, ybar, gamma, eps, xbar, dgamma, dbeta, dxsum, partial, rows, H,
                              (hipStream_t)stream);
 }
 
@@ -594,10 +596,12 @@ extern "C" int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, in
   hipStream_t st = (hipStream_t)stream;
   const int E = dtype == PG_F32 ? 4 : 8;
   if (ld % E == 0 && N % E == 0 && ((uintptr_t)dY) % 16 == 0) {
-    // about four workgroups per CU in flight: 32 rows (8 per wave) per chunk unless that is too many chunks
+    // at most 32 row chunks: every chunk ends in one atomic per column, and many workgroups adding
+    // into the same few KiB at once serialise
     const int gx = (N + 64 * E - 1) / (64 * E);
-    int rpc = 32;
-    while ((long)gx * ((rows + rpc - 1) / rpc) > 2048) rpc *= 2;
+    int chunks = rows / 64;
+    chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
+    const int rpc = ((rows + chunks - 1) / chunks + 3) / 4 * 4;
     dim3 grid(gx, (rows + rpc - 1) / rpc);
     if (dtype == PG_F32)
       hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, (long)ld, rows, N, db, rpc);

@@ -94,15 +94,15 @@ def layernorm(x, gamma, beta, eps):
 
 
 def _ln_partial(rows, H, device):
-    return torch.empty(2 * H * lib.pg_ln_partial_rows(rows), dtype=torch.float32, device=device)
+    return torch.empty(3 * H * lib.pg_ln_partial_rows(rows), dtype=torch.float32, device=device)
 
 
-def layernorm_bwd(x, dy, gamma, eps, dgamma=None, dbeta=None):
+def layernorm_bwd(x, dy, gamma, eps, dgamma=None, dbeta=None, dxsum=None):
     dx = torch.empty_like(x)
     rows, H = x.numel() // x.shape[-1], x.shape[-1]
-    part = _ln_partial(rows, H, x.device) if (dgamma is not None or dbeta is not None) else None
+    part = _ln_partial(rows, H, x.device) if any(t is not None for t in (dgamma, dbeta, dxsum)) else None
     check(lib.pg_layernorm_bwd(dt_code(x.dtype), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), eps, dx.data_ptr(),
-                               ptr(dgamma), ptr(dbeta), ptr(part), rows, H, stream()), "pg_layernorm_bwd")
+                               ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(part), rows, H, stream()), "pg_layernorm_bwd")
     return dx
 
 
@@ -114,13 +114,13 @@ def layernorm_jvp(x, xdot, gamma, eps):
     return y
 
 
-def layernorm_bwd2(x, xdot, gy, ybar, gamma, eps, dgamma=None, dbeta=None):
+def layernorm_bwd2(x, xdot, gy, ybar, gamma, eps, dgamma=None, dbeta=None, dxsum=None):
     xbar = torch.empty_like(x)
     rows, H = x.numel() // x.shape[-1], x.shape[-1]
-    part = _ln_partial(rows, H, x.device) if (dgamma is not None or dbeta is not None) else None
+    part = _ln_partial(rows, H, x.device) if any(t is not None for t in (dgamma, dbeta, dxsum)) else None
     check(lib.pg_layernorm_bwd2(dt_code(x.dtype), x.data_ptr(), xdot.data_ptr(), gy.data_ptr(), ptr(ybar),
-                                gamma.data_ptr(), eps, xbar.data_ptr(), ptr(dgamma), ptr(dbeta), ptr(part), rows, H,
-                                stream()), "pg_layernorm_bwd2")
+                                gamma.data_ptr(), eps, xbar.data_ptr(), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(part),
+                                rows, H, stream()), "pg_layernorm_bwd2")
     return xbar
 
 

@@ -220,18 +220,26 @@ def test_layernorm_family(pg, dtype, H):
     close(pg.ops.layernorm(d(x), gd, bd, eps), K.ln_fwd(x.double(), gam.double(), bet.double(), eps), dtype)
     dg = torch.full((H,), 0.5, device=DEV)
     db = torch.full((H,), -0.25, device=DEV)
-    dx = pg.ops.layernorm_bwd(d(x), d(gy), gd, eps, dg, db)
+    dxs = torch.full((H,), 2.0, device=DEV)
+    dx = pg.ops.layernorm_bwd(d(x), d(gy), gd, eps, dg, db, dxs)
     rdx, rdg, rdb = K.ln_bwd(x.double(), gy.double(), gam.double(), eps)
     close(dx, rdx, dtype)
     close(dg, rdg + 0.5, torch.float32, mult=10)
     close(db, rdb - 0.25, torch.float32, mult=10)
+    # column sums of the output (the bias gradient of the Linear in front): sums of the fp32 values
+    close(dxs, rdx.sum(0) + 2.0, torch.float32, scale=float(rdx.abs().sum(0).max()), mult=10)
+    only = torch.zeros(H, device=DEV)
+    pg.ops.layernorm_bwd(d(x), d(gy), gd, eps, None, None, only)
+    close(only, rdx.sum(0), torch.float32, scale=float(rdx.abs().sum(0).max()), mult=10)
     close(pg.ops.layernorm_jvp(d(x), d(xdot), gd, eps), K.ln_jvp(x.double(), xdot.double(), gam.double(), eps), dtype)
     for yb in (ybar, None):
         dg.zero_()
         db.zero_()
-        xb = pg.ops.layernorm_bwd2(d(x), d(xdot), d(gy), None if yb is None else d(yb), gd, eps, dg, db)
+        dxs.zero_()
+        xb = pg.ops.layernorm_bwd2(d(x), d(xdot), d(gy), None if yb is None else d(yb), gd, eps, dg, db, dxs)
         rx, rg, rb = K.ln_bwd2(x.double(), xdot.double(), gy.double(), None if yb is None else yb.double(), gam.double(), eps)
         close(xb, rx, dtype, mult=2)
+        close(dxs, rx.sum(0), torch.float32, scale=float(rx.abs().sum(0).max()), mult=20)
         close(dg, rg, torch.float32, mult=20)
         close(db, rb, torch.float32, scale=max(float(rb.abs().max()), 1.0), mult=20)
 
