@@ -1130,6 +1130,8 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a);
 ProfEntry* prof_begin(int variant, double flops, hipStream_t st);
 }  // namespace
 
+static long tiles256(const pg_gemm_desc* d) { return (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch; }
+
 extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   GemmArgs a;
   const int prc = gemm_prepare(d, a);
@@ -1145,8 +1147,10 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
     if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
     else rc = launch_glds_n64<bf16_t>(d, a, st);
-  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide == 1 && d->N >= 2048 &&
-                      (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch >= 160))) {
+  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
+                      // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
+                      // traffic outweighs the partial last round
+                      (g_gemm_wide == 1 && d->N >= 512 && d->K >= 2048 && tiles256(d) >= 512))) {
     if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
     else rc = launch_glds256<bf16_t>(d, a, st);
   } else if (fast) {
