@@ -42,19 +42,28 @@ __device__ __forceinline__ float gelu_d2(float x) {
   return pdf * (2.0f - x * x);
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): used where the result is rounded
-// to bf16 anyway; the fp32 path keeps the library erff.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - p * __expf(-ax * ax);
-  return copysignf(r, x);
+// GELU for values that are rounded to bf16 anyway (GEMM epilogues of the bf16 path; the fp32 path
+// keeps the library erff):  gelu(x) ~= x * sigmoid(t(x)),  t = x (a + b x^2 + c x^4), a minimax fit
+// to the erf form over the real line: |error| <= 2.6e-5 for the value and <= 1.1e-4 for the first
+// derivative (a bf16 rounding step is 3.9e-3 relative).  c < 0, so t is evaluated on x clamped to
+// [-8, 8], where the sigmoid has long saturated.  Seven 4-cycle VALU operations, one v_exp_f32 and
+// one v_rcp_f32 per value, against fifteen plus two for a rational erf.
+constexpr float GELU_SIG_A = 1.59501577f, GELU_SIG_B = 7.40112920e-2f, GELU_SIG_C = -7.03033578e-4f;
+constexpr float NEG_LOG2E = -1.44269504088896340736f;
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  const float q = fmaf(x2, fmaf(x2, GELU_SIG_C * NEG_LOG2E, GELU_SIG_B * NEG_LOG2E), GELU_SIG_A * NEG_LOG2E);
+  const float e = __builtin_amdgcn_exp2f(xc * q);  // exp(-t)
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_d1_fast(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-  return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  const float q = fmaf(x2, fmaf(x2, GELU_SIG_C * NEG_LOG2E, GELU_SIG_B * NEG_LOG2E), GELU_SIG_A * NEG_LOG2E);
+  const float tp = fmaf(x2, fmaf(x2, 5.0f * GELU_SIG_C, 3.0f * GELU_SIG_B), GELU_SIG_A);  // dt/dx
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * q));
+  return fmaf(x * tp, s - s * s, s);
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so hardware ids b and

@@ -10,8 +10,8 @@ from protgen_gan_amd._lib import lib
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 T = 4096
-shapes = [("wo", T, 1024, 1024), ("w2", T, 1024, 4096), ("dx", T, 1024, 3072)]
-lib.pg_tune(2, 0)
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+shapes = [("qkv", T, 3072, 1024), ("wo", T, 1024, 1024), ("w1", T, 4096, 1024), ("w2", T, 1024, 4096)]
 
 
 def timed(fn, n=120):
@@ -26,7 +26,7 @@ def timed(fn, n=120):
 
 
 for name, M, N, K in shapes:
-    nA = max(2, min(24, int(400e6 // (M * K * 2))))
+    nA = max(2, min(24, int(600e6 // (M * K * 2))))
     As = [torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16) for _ in range(nA)]
     Bs = [(torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16) for _ in range(30)]
     C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
@@ -35,8 +35,9 @@ for name, M, N, K in shapes:
         a = (lambda i: As[0]) if hot else (lambda i: As[i % nA])
         b = (lambda i: Bs[0]) if hot else (lambda i: Bs[i % 30])
         row = []
-        for path in (2, 4, 5):
+        for path in (2, 4):
             lib.pg_tune(0, path)
+            lib.pg_tune(2, 0)
             us = timed(lambda i: pg.ops.gemm(a(i), b(i), C))
             row.append(f"glds{path} {us:6.1f} us {fl/us/1e6:5.0f} TF")
         lib.pg_tune(0, 1)
