@@ -145,15 +145,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, 
                                                       const float* __restrict__ gamma, float eps, T* __restrict__ xbar,
                                                       float* __restrict__ partial, int rows, int H, int n_waves) {
   constexpr int N = VW * NCH;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (wave >= n_waves) return;
+  __shared__ float red[ROWS_PER_BLOCK - 1][64 * N];  // waves 1.. park one partial array at a time
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int wave = blockIdx.x * ROWS_PER_BLOCK + wib;
   float g[N], dg[N], db[N], dxs[N];
   row_load<float, VW, NCH>(gamma, lane, g);
 #pragma unroll
   for (int i = 0; i < N; ++i) { dg[i] = 0.f; db[i] = 0.f; dxs[i] = 0.f; }
   const float invH = 1.0f / (float)H;
-  for (long row = wave; row < rows; row += n_waves) {
+  for (long row = wave; row < rows; row += n_waves) {  // (waves past n_waves own no row)
     float x[N], out[N];
     row_load<T, VW, NCH>(xin + row * H, lane, x);
     float mean, rstd;
@@ -211,11 +211,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ xin, 
 #pragma unroll
     for (int i = 0; i < N; ++i) dxs[i] += out[i];
   }
-  if (partial) {
-    float* pg = partial + (long)wave * 3 * H;
-    row_store<float, VW, NCH>(pg, lane, dg);
-    row_store<float, VW, NCH>(pg + H, lane, db);
-    row_store<float, VW, NCH>(pg + 2 * H, lane, dxs);
+  if (partial) {  // one partial row per workgroup: the four waves combine through LDS first
+    float* pg = partial + (long)blockIdx.x * 3 * H;
+#pragma unroll
+    for (int arr = 0; arr < 3; ++arr) {
+      float(&v)[N] = arr == 0 ? dg : (arr == 1 ? db : dxs);
+      if (wib > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[wib - 1][i * 64 + lane] = v[i];
+      }
+      __syncthreads();
+      if (wib == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+          for (int w = 0; w < ROWS_PER_BLOCK - 1; ++w) v[i] += red[w][i * 64 + lane];
+        }
+        row_store<float, VW, NCH>(pg + arr * H, lane, v);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -537,8 +552,10 @@ int ln_bwd_launch(int dtype, const void* x, const void* xdot, const void* gy, co
                   hipStream_t st) {
   const bool want_params = dgamma || dbeta || dxsum;
   if (want_params && !partial) return PG_ERR_WORKSPACE;
-  const int n_waves = pg_ln_partial_rows(rows);
-  const int blocks = row_blocks(n_waves);
+  // up to 1024 workgroups of four waves (16 waves per CU keep enough rows in flight); one partial
+  // row per workgroup, so the scratch stays at pg_ln_partial_rows(rows) rows
+  const int blocks = rows < 4096 ? row_blocks(rows) : 1024;
+  const int n_waves = blocks * ROWS_PER_BLOCK;
   float* part = want_params ? partial : nullptr;
   if (dtype == PG_F32) {
     ROW_DISPATCH(H, hipLaunchKernelGGL((ln_bwd_kernel<float, VW, NCH, SECOND>), dim3(blocks), dim3(256), 0, st,
@@ -551,10 +568,10 @@ int ln_bwd_launch(int dtype, const void* x, const void* xdot, const void* gy, co
   }
   if (hipGetLastError() != hipSuccess) return PG_ERR_LAUNCH;
   if (want_params) {
-    int chunks = (n_waves + 63) / 64;
+    int chunks = (blocks + 63) / 64;
     if (chunks > 16) chunks = 16;
-    const int rpc = (n_waves + chunks - 1) / chunks;
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((3 * H + 63) / 64, chunks), dim3(256), 0, st, partial, n_waves, H,
+    const int rpc = (blocks + chunks - 1) / chunks;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((3 * H + 63) / 64, chunks), dim3(256), 0, st, partial, blocks, H,
                        dgamma, dbeta, dxsum, rpc);
   }
   return check_launch();
