@@ -94,6 +94,10 @@ typedef struct {
   void* aux; int64_t ldaux;
   void* aux2; /* PG_ACT_MUL_DGELU only: optional store of v before the multiply (ld = ldaux) */
   int act;
+  /* Optional second reduction segment (unbatched only): C = epilogue(alpha (A.B + A2.B2)), A2 / B2 in
+   * the layout and leading dimensions of A / B with reduction extent K2 (0 = none).  The gradient
+   * penalty's second-order pass sums two products into each weight gradient. */
+  const void* A2; const void* B2; int K2;
 } pg_gemm_desc;
 int pg_gemm(const pg_gemm_desc* d, void* stream);
 /* Two unbatched products in one launch (results identical to pg_gemm(d0) then pg_gemm(d1)):
@@ -107,7 +111,7 @@ int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void* stream);
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
-int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1); key 6: fused attention kernels in the gradient-penalty passes (0/1) */
+int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1); key 6: fused attention kernels in the gradient-penalty passes (0/1); key 7: two-segment products in one launch (0/1) */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 

@@ -37,7 +37,8 @@ class GemmDesc(C.Structure):
                 ("sCo", C.c_int64), ("sCi", C.c_int64),
                 ("alpha", C.c_float), ("beta", C.c_float),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
-                ("aux", C.c_void_p), ("ldaux", C.c_int64), ("aux2", C.c_void_p), ("act", C.c_int)]
+                ("aux", C.c_void_p), ("ldaux", C.c_int64), ("aux2", C.c_void_p), ("act", C.c_int),
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int)]
 
 
 if not os.path.exists(LIB_PATH):

@@ -130,22 +130,19 @@ struct G {
     d.aux2 = aux2; d.act = act;
     return pg_gemm(&d, st);
   }
-  // Two weight gradients dW += dY^T X (fp32 accumulate) in one launch.
-  int dw_pair(const void* dY0, long ld0, const void* X0, long ldx0, float* dW0, int No0, int Ni0, const void* dY1, long ld1,
-              const void* X1, long ldx1, float* dW1, int No1, int Ni1, int T) const {
-    pg_gemm_desc d[2];
-    memset(d, 0, sizeof(d));
-    const void* A[2] = {dY0, dY1}; const void* B[2] = {X0, X1}; float* C[2] = {dW0, dW1};
-    const long lda[2] = {ld0, ld1}, ldb[2] = {ldx0, ldx1};
-    const int M[2] = {No0, No1}, N[2] = {Ni0, Ni1};
-    for (int i = 0; i < 2; ++i) {
-      d[i].A = A[i]; d[i].B = B[i]; d[i].C = C[i]; d[i].dtype = dtype; d[i].c_dtype = PG_F32;
-      d[i].a_kmajor = 0; d[i].b_kmajor = 0; d[i].M = M[i]; d[i].N = N[i]; d[i].K = T;
-      d[i].lda = lda[i]; d[i].ldb = ldb[i]; d[i].ldc = N[i]; d[i].batch = 1; d[i].batch_inner = 1;
-      d[i].alpha = 1.f; d[i].beta = 1.f;
-    }
-    return pg_gemm_pair(&d[0], &d[1], st);
+  // dW += dY^T X (+ dYb^T Xb when a second operand pair is given), fp32 accumulate.
+  pg_gemm_desc dw_desc(const void* dY, const void* X, float* dW, int No, int Ni, int T, const void* dYb = nullptr,
+                       const void* Xb = nullptr) const {
+    pg_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = dY; d.B = X; d.C = dW; d.dtype = dtype; d.c_dtype = PG_F32; d.a_kmajor = 0; d.b_kmajor = 0;
+    d.M = No; d.N = Ni; d.K = T; d.lda = No; d.ldb = Ni; d.ldc = Ni; d.batch = 1; d.batch_inner = 1;
+    d.alpha = 1.f; d.beta = 1.f;
+    if (dYb) { d.A2 = dYb; d.B2 = Xb; d.K2 = T; }
+    return d;
   }
+  int dw(const pg_gemm_desc& d) const { return pg_gemm(&d, st); }
+  int dw_pair(const pg_gemm_desc& d0, const pg_gemm_desc& d1) const { return pg_gemm_pair(&d0, &d1, st); }
   // Batched over (b, head).  Operands living in a [T][ld] activation buffer are addressed with
   // (outer = S*ld, inner = 64); score-shaped operands with (outer = nh*S*ldS, inner = S*ldS).
   int bat(const Dims& dm, const void* A, bool ak, long lda, bool a_score, const void* B, bool bk, long ldb, bool b_score,
@@ -421,7 +418,8 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              0.f));
     if (grads) {
-      CK(g.dw_pair(a.a, H, s.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, a.qkv, 3 * H, s.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
+      CK(g.dw_pair(g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T),
+                   g.dw_desc(a.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T)));
       CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // dx = dqkv Wqkv + da
@@ -516,15 +514,13 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
                          grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
                          grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
     if (grads) {
-      CK(g.run(w.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
-      CK(g.run(a.f, false, H, t.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
+      CK(g.dw(g.dw_desc(w.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu)));  // W2bar = fbar^T gu + gf^T gudot
     }
     // gubar = fbar W2 ; ubar = gelu'(u) gubar + gelu''(u) udot ggu
     CK(g.run(w.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
     CK(pg_gelu_bwd2(dtype, s.u, t.u, a.gu, w.gu, w.u, (int64_t)d.T * I, st));
     if (grads) {
-      CK(g.run(w.u, false, I, s.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
-      CK(g.run(a.u, false, I, t.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
+      CK(g.dw(g.dw_desc(w.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h)));
       CK(pg_colsum_acc(dtype, w.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
     }
     // hbar = ubar W1 + fbar
@@ -563,8 +559,8 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              1.f));
     if (grads) {
-      CK(g.dw_pair(w.a, H, s.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, w.qkv, 3 * H, s.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
-      CK(g.dw_pair(a.a, H, t.ctx, H, pv.g(pv.lo(l, PG_L_WO)), H, H, a.qkv, 3 * H, t.x, H, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T));
+      CK(g.dw_pair(g.dw_desc(w.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx),
+                   g.dw_desc(w.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T, a.qkv, t.x)));
       CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // xbar = qkvbar Wqkv + abar

@@ -60,6 +60,7 @@ struct GemmArgs {
   void* aux2;
   int act;
   int vec_ok;
+  const void* A2; const void* B2; int K2;  // optional second reduction segment (same layout and strides)
 };
 
 // ---- global -> register staging of one operand tile -------------------------------------
@@ -657,20 +658,26 @@ __device__ __forceinline__ void glds_body(bf16_t* smem, const GemmArgs& g, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = g.K / GBK;
+  // k-tiles [0, nt1) come from (A, B), k-tiles [nt1, nt) from the optional second segment (A2, B2)
+  const int nt1 = g.K / GBK, nt = nt1 + g.K2 / GBK;
+  const bf16_t* A2 = reinterpret_cast<const bf16_t*>(g.A2);
+  const bf16_t* B2 = reinterpret_cast<const bf16_t*>(g.B2);
+  auto stage = [&](int t, bf16_t* dst) {
+    const bool second = t >= nt1;
+    const int k0 = (second ? t - nt1 : t) * GBK;
+    glds_stage<AK>(second ? A2 : A, g.lda, bm, g.M, k0, dst, wid, lane);
+    glds_stage<BK_>(second ? B2 : B, g.ldb, bn, g.N, k0, dst + GT_ELEMS, wid, lane);
+  };
   const FragOff<AK> fa = frag_offsets<AK>(wr, lane);
   const FragOff<BK_> fb = frag_offsets<BK_>(wc, lane);
   const unsigned smem_addr = lds_addr(smem);
   if constexpr (NST == 2) {
-    glds_stage<AK>(A, g.lda, bm, g.M, 0, smem, wid, lane);
-    glds_stage<BK_>(B, g.ldb, bn, g.N, 0, smem + GT_ELEMS, wid, lane);
+    stage(0, smem);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
       const unsigned la = smem_addr + (t & 1) * 4 * GT_ELEMS;
       if (t + 1 < nt) {
-        bf16_t* na = smem + ((t + 1) & 1) * 2 * GT_ELEMS;
-        glds_stage<AK>(A, g.lda, bm, g.M, (t + 1) * GBK, na, wid, lane);
-        glds_stage<BK_>(B, g.ldb, bn, g.N, (t + 1) * GBK, na + GT_ELEMS, wid, lane);
+        stage(t + 1, smem + ((t + 1) & 1) * 2 * GT_ELEMS);
       }
       glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
       __syncthreads();
@@ -679,9 +686,7 @@ __device__ __forceinline__ void glds_body(bf16_t* smem, const GemmArgs& g, const
     // every wave issues 8 LDS-DMA loads per k-tile; vmcnt(8 * tiles allowed to stay in flight)
     const int pre = nt < NST - 1 ? nt : NST - 1;
     for (int t = 0; t < pre; ++t) {
-      bf16_t* na = smem + t * 2 * GT_ELEMS;
-      glds_stage<AK>(A, g.lda, bm, g.M, t * GBK, na, wid, lane);
-      glds_stage<BK_>(B, g.ldb, bn, g.N, t * GBK, na + GT_ELEMS, wid, lane);
+      stage(t, smem + t * 2 * GT_ELEMS);
     }
     for (int t = 0; t < nt; ++t) {
       const int ahead = nt - 1 - t;  // tiles issued after tile t that may remain in flight
@@ -690,9 +695,7 @@ __device__ __forceinline__ void glds_body(bf16_t* smem, const GemmArgs& g, const
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // tile t landed for every wave; buffer (t-1)%NST is free again
       if (t + NST - 1 < nt) {
-        bf16_t* na = smem + ((t + NST - 1) % NST) * 2 * GT_ELEMS;
-        glds_stage<AK>(A, g.lda, bm, g.M, (t + NST - 1) * GBK, na, wid, lane);
-        glds_stage<BK_>(B, g.ldb, bn, g.N, (t + NST - 1) * GBK, na + GT_ELEMS, wid, lane);
+        stage(t + NST - 1, smem + ((t + NST - 1) % NST) * 2 * GT_ELEMS);
       }
       const unsigned la = smem_addr + (t % NST) * 4 * GT_ELEMS;
       glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
@@ -1108,6 +1111,7 @@ int g_gemm_wide = 1;  // 1 = 256x256 tiles for large-N products with enough tile
 
 int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte accesses only)
 int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
+int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1122,6 +1126,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 4) { g_gemm_ep8 = value; return PG_OK; }
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
+  if (key == 7) { g_gemm_dualk = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 
@@ -1138,19 +1143,32 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (prc != PG_OK) return prc;
   dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
   hipStream_t st = (hipStream_t)stream;
-  ProfEntry* pe = prof_begin((d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0),
-                             2.0 * d->M * d->N * (double)d->K * d->batch, st);
-  int rc = PG_ERR_ARG;
-  const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
+  const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && d->K2 % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
                     (d->b_kmajor || d->N >= 8);
   const long blocks128 = (long)grid.x * grid.y * grid.z;
-  if (fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256))) {
+  const bool narrow = fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256));
+  const bool wide = fast && !narrow &&
+                    (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
+                     // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
+                     // traffic outweighs the partial last round
+                     (g_gemm_wide == 1 && d->N >= 512 && d->K >= 2048 && tiles256(d) >= 512));
+  if (d->K2 > 0 && (!fast || narrow || wide || !g_gemm_dualk)) {
+    // only the 128x128 direct-to-LDS kernel walks two reduction segments: elsewhere two launches
+    if (d->bias || d->residual || d->act != PG_ACT_NONE) return PG_ERR_UNSUPPORTED;  // the epilogue would apply twice
+    pg_gemm_desc one = *d;
+    one.K2 = 0; one.A2 = nullptr; one.B2 = nullptr;
+    const int rc1 = pg_gemm(&one, stream);
+    if (rc1 != PG_OK) return rc1;
+    one.A = d->A2; one.B = d->B2; one.K = d->K2; one.beta = 1.f;
+    return pg_gemm(&one, stream);
+  }
+  ProfEntry* pe = prof_begin((d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0),
+                             2.0 * d->M * d->N * ((double)d->K + d->K2) * d->batch, st);
+  int rc = PG_ERR_ARG;
+  if (narrow) {
     if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
     else rc = launch_glds_n64<bf16_t>(d, a, st);
-  } else if (fast && (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
-                      // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
-                      // traffic outweighs the partial last round
-                      (g_gemm_wide == 1 && d->N >= 512 && d->K >= 2048 && tiles256(d) >= 512))) {
+  } else if (wide) {
     if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
     else rc = launch_glds256<bf16_t>(d, a, st);
   } else if (fast) {
@@ -1212,6 +1230,16 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
   a.bias = d->bias; a.residual = d->residual; a.ldr = d->ldr; a.aux = d->aux; a.ldaux = d->ldaux;
   a.aux2 = d->act == PG_ACT_MUL_DGELU ? d->aux2 : nullptr;
   a.act = d->act;
+  a.A2 = nullptr; a.B2 = nullptr; a.K2 = 0;
+  if (d->K2 > 0) {
+    if (!d->A2 || !d->B2 || d->batch != 1) return PG_ERR_ARG;
+    if (((uintptr_t)d->A2 | (uintptr_t)d->B2) & 15) return PG_ERR_ALIGN;
+    if (d->a_kmajor && d->lda < ((d->K2 + epc - 1) / epc) * epc) return PG_ERR_ARG;
+    if (d->b_kmajor && d->ldb < ((d->K2 + epc - 1) / epc) * epc) return PG_ERR_ARG;
+    a.A2 = d->A2; a.B2 = d->B2; a.K2 = d->K2;
+  } else if (d->K2 < 0) {
+    return PG_ERR_ARG;
+  }
   const int csz = d->c_dtype == PG_F32 ? 4 : 2;
   const int tsz = d->dtype == PG_F32 ? 4 : 2;
   bool vec = (d->ldc % 4 == 0) && (d->sCo % 4 == 0) && (d->sCi % 4 == 0) && (((uintptr_t)d->C) % (4 * csz) == 0);
@@ -1240,10 +1268,11 @@ extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void
   rc = gemm_prepare(d1, a.p1);
   if (rc != PG_OK) return rc;
   auto fast = [](const pg_gemm_desc* d) {
-    return d->dtype == PG_BF16 && d->K % GBK == 0 && d->batch == 1 && d->N > 64 && (d->a_kmajor || d->M >= 8) &&
-           (d->b_kmajor || d->N >= 8);
+    return d->dtype == PG_BF16 && d->K % GBK == 0 && d->K2 % GBK == 0 && d->batch == 1 && d->N > 64 &&
+           (d->a_kmajor || d->M >= 8) && (d->b_kmajor || d->N >= 8);
   };
-  const bool together = g_gemm_path != 0 && g_gemm_pair != 0 && fast(d0) && fast(d1) && d0->a_kmajor == d1->a_kmajor &&
+  const bool seg_ok = (d0->K2 == 0 && d1->K2 == 0) || g_gemm_dualk != 0;
+  const bool together = g_gemm_path != 0 && g_gemm_pair != 0 && seg_ok && fast(d0) && fast(d1) && d0->a_kmajor == d1->a_kmajor &&
                         d0->b_kmajor == d1->b_kmajor && d0->c_dtype == d1->c_dtype;
   if (!together) {
     rc = pg_gemm(d0, stream);
@@ -1255,7 +1284,7 @@ extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void
   const int blocks = a.nb0 + a.gx1 * ((d1->M + BM - 1) / BM);
   hipStream_t st = (hipStream_t)stream;
   ProfEntry* pe = prof_begin(8 + (d0->c_dtype == PG_F32 ? 4 : 0) + (d0->a_kmajor ? 2 : 0) + (d0->b_kmajor ? 1 : 0),
-                             2.0 * d0->M * d0->N * (double)d0->K + 2.0 * d1->M * d1->N * (double)d1->K, st);
+                             2.0 * d0->M * d0->N * ((double)d0->K + d0->K2) + 2.0 * d1->M * d1->N * ((double)d1->K + d1->K2), st);
   const int kmin = d0->K < d1->K ? d0->K : d1->K;
   const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && kmin >= 4 * GBK);
   if (deep) rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 4>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 4>(d0, a, blocks, st);

@@ -62,8 +62,9 @@ def gemm_pair(A0, B0, C0, A1, B1, C1, *, a_kmajor=True, b_kmajor=True, alpha=1.0
 
 
 def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alpha=1.0, beta=0.0, bias=None,
-         residual=None, act=PG_ACT_NONE, aux=None, aux2=None):
-    """2-D GEMM.  A is [M,K] (a_kmajor) or [K,M]; B is [N,K] (b_kmajor) or [K,N]."""
+         residual=None, act=PG_ACT_NONE, aux=None, aux2=None, A2=None, B2=None):
+    """2-D GEMM.  A is [M,K] (a_kmajor) or [K,M]; B is [N,K] (b_kmajor) or [K,N].  (A2, B2): an
+    optional second reduction segment with the row strides of (A, B): C = epilogue(alpha (A.B + A2.B2))."""
     _need_cuda(A, B)
     M, K = (A.shape if a_kmajor else (A.shape[1], A.shape[0]))
     N, K2 = (B.shape if b_kmajor else (B.shape[1], B.shape[0]))
@@ -81,6 +82,11 @@ def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alph
     if aux2 is not None:
         d.aux2 = aux2.data_ptr()
     d.act = act
+    if A2 is not None:
+        assert A2.stride(0) == A.stride(0) and B2.stride(0) == B.stride(0) and A2.stride(1) == 1 and B2.stride(1) == 1
+        K2 = A2.shape[1] if a_kmajor else A2.shape[0]
+        assert K2 == (B2.shape[1] if b_kmajor else B2.shape[0])
+        d.A2, d.B2, d.K2 = A2.data_ptr(), B2.data_ptr(), K2
     check(lib.pg_gemm(C.byref(d), stream()), "pg_gemm")
     return C_out
 

@@ -196,6 +196,24 @@ def test_gemm_pair_weight_gradients(pg, dtype, T):
     assert torch.equal(c0, e0) and torch.equal(c1, e1)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,T2", [(256, 192), (328, 64)])
+def test_gemm_two_reduction_segments(pg, dtype, T, T2):
+    """dW += dY^T X + dYb^T Xb as one descriptor (the second-order pass's weight gradients):
+    whole-k-tile bf16 walks both segments in one launch, everything else falls back to two."""
+    g = torch.Generator().manual_seed(32)
+    dY, X = rnd(T, 136, dtype=dtype, gen=g), rnd(T, 200, dtype=dtype, gen=g)
+    dYb, Xb = rnd(T2, 136, dtype=dtype, gen=g), rnd(T2, 200, dtype=dtype, gen=g)
+    C0 = torch.randn(136, 200, generator=g)
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    c = C0.clone().to(DEV)
+    pg.ops.gemm(d(dY), d(X), c, a_kmajor=False, b_kmajor=False, beta=1.0, A2=d(dYb), B2=d(Xb))
+    close(c, C0.double() + dY.double().T @ X.double() + dYb.double().T @ Xb.double(), dtype)
+    with pytest.raises(pg._lib.PgError):  # an epilogue cannot be split over two launches
+        pg.ops.gemm(d(dY)[:, :56].contiguous(), d(X)[:, :56].contiguous(), None, a_kmajor=False, b_kmajor=False,
+                    bias=torch.zeros(56, device=DEV), A2=d(dYb)[:, :56].contiguous(), B2=d(Xb)[:, :56].contiguous())
+
+
 def test_gemm_rejects_bad_arguments(pg):
     with pytest.raises(pg._lib.PgError):  # fp32 leading dimension not a multiple of 4 elements
         pg.ops.gemm(torch.zeros(64, 34, device=DEV), torch.zeros(64, 34, device=DEV))
