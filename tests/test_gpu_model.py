@@ -430,3 +430,79 @@ def test_bf16_generation_runs_and_is_plausible(pg):
     torch.manual_seed(3)
     out = gen_py.generate_full_mode_sequences(gen, pg.ProtTokenizer(), 6, [37, 45, 51], batch_size=4, device=DEV, rng_seed=1)
     assert len(out) == 6 and all(isinstance(s, str) for s in out)
+
+
+# ----------------------------------------------------------------------------- full-size ProtBERT
+FULL = O.BertCfg(max_position_embeddings=640)  # 30 x 1024 x 16 heads x 4096, vocab 30
+
+
+@pytest.fixture(scope="module")
+def full_params():
+    return O.init_params(FULL, seed=7, bias_std=0.02), O.init_classifier(FULL.hidden_size, seed=8)
+
+
+def test_full_size_critic_step_fp32_vs_oracle(pg, full_params):
+    """The full 30-layer, 1024-wide model (short sequences so the CPU oracle's autograd double
+    backward finishes in seconds): scores, gp, loss and a spread of parameter gradients of one
+    critic update in fp32."""
+    PC, C = full_params
+    critic = pg.Critic(pg.ProtBertForMaskedLM.from_params(make_cfg(pg, FULL), PC, device=DEV, compute_dtype=torch.float32))
+    critic.classifier.load_state_dict(C)
+    g = torch.Generator().manual_seed(11)
+    B, S = 2, 24
+    real = torch.randint(5, 25, (B, S), generator=g)
+    fake = torch.randint(5, 25, (B, S), generator=g)
+    real[:, 0] = fake[:, 0] = O.CLS
+    rm = torch.ones(B, S)
+    rm[1, 19:] = 0
+    real[1, 19:] = O.PAD
+    fm = (fake != O.PAD).long()
+    alpha = torch.rand(B, 1, 1, generator=g)
+    loss, gp, rs, fs, grads = O.critic_step_grads(PC, C, FULL, real, fake, rm, fm, alpha, 5.0)
+    critic.zero_grad(set_to_none=True)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    gp_h = pg.compute_gradient_penalty(critic, d(real), d(fake), d(rm), d(fm), DEV, alpha=alpha)
+    rs_h, fs_h = critic(d(real), attention_mask=d(rm)), critic(d(fake), attention_mask=d(fm))
+    l_h = pg.critic_loss(rs_h, fs_h, gp_h, 5.0)
+    l_h.backward()
+    rel_close(rs_h.detach().cpu().numpy(), rs.detach().numpy(), 1e-4, "real scores")
+    rel_close(fs_h.detach().cpu().numpy(), fs.detach().numpy(), 1e-4, "fake scores")
+    rel_close(gp_h.item(), gp.detach().numpy(), 5e-4, "gp")
+    rel_close(l_h.item(), loss.detach().numpy(), 5e-4, "loss")
+    named = dict(critic.named_parameters())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    picked = [n for n in grads if any(k in n for k in ("layer.0.", "layer.14.", "layer.29.", "embeddings", "classifier"))]
+    assert len(picked) > 40
+    for n in picked:
+        rel_close(named[n].grad.cpu().numpy(), grads[n].numpy(), 5e-3, f"grad {n}", atol=2e-6 * gmax)
+
+
+def test_full_size_stacked_fill_bf16(pg, full_params):
+    """Full-size generator in bf16: three blind-mode batches of different widths filled as one
+    stacked batch give the very tokens of three separate generate() calls (rows never interact,
+    and every kernel sums a row's products in the same order whatever the batch shape)."""
+    P, _ = full_params
+    gen = pg.Generator(pg.ProtBertForMaskedLM.from_params(make_cfg(pg, FULL), P, device=DEV, compute_dtype=torch.bfloat16))
+    V = FULL.vocab_size
+    g = torch.Generator().manual_seed(12)
+    widths, lens = [40, 64, 56], [[40, 31], [64, 50, 20], [56]]
+    parts = [_blind_template(ls, w).to(DEV) for ls, w in zip(lens, widths)]
+    rows, W = sum(len(x) for x in lens), max(widths)
+    st = torch.full((rows, W), O.PAD, dtype=torch.long, device=DEV)
+    inside = torch.zeros(rows, W, dtype=torch.bool, device=DEV)
+    spans, r = [], 0
+    for p, w in zip(parts, widths):
+        st[r:r + p.size(0), :w] = p
+        inside[r:r + p.size(0), :w] = True
+        spans.append((r, r + p.size(0)))
+        r += p.size(0)
+    temps = [0.85, 1.0, 1.15]
+    for rate in (0.9, 0.5, 0.1):
+        ns = torch.empty(rows, W, V).exponential_(1.0, generator=g)
+        for i, (p, w, (a, b)) in enumerate(zip(parts, widths, spans)):
+            parts[i] = gen.generate(p, (p != O.MASK).long(), temperature=temps[i], keep_percent=0.3, current_rate=rate,
+                                    noise=ns[a:b, :w].reshape(-1, V))
+        st = gen.generate_groups(st, ((st != O.MASK) & inside).long(), [(a, b, t) for (a, b), t in zip(spans, temps)],
+                                 keep_percent=0.3, current_rate=rate, noise=ns.view(rows * W, V))
+        for p, w, (a, b) in zip(parts, widths, spans):
+            assert torch.equal(st[a:b, :w], p)
