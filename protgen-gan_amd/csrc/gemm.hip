@@ -61,6 +61,7 @@ struct GemmArgs {
   int act;
   int vec_ok;
   const void* A2; const void* B2; int K2;  // optional second reduction segment (same layout and strides)
+  int group_m;  // tile rows per group of the grouped tile order (1 = row-major)
 };
 
 // ---- global -> register staging of one operand tile -------------------------------------
@@ -715,7 +716,13 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_glds_kernel(G
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  glds_body<TC, AK, BK_, NST>(smem, g, A, B, Cp, (txy / gridDim.x) * BM, (txy % gridDim.x) * BN);
+  // wide outputs (more than eight tile columns): groups of eight tile rows walked down the rows
+  // first, so that the workgroups an XCD runs together share operand panels in its L2
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int GM = gx > 8 ? g.group_m : 1;
+  const int grp = txy / (GM * gx), first = grp * GM, rem = txy - grp * GM * gx;
+  const int gsz = gy - first < GM ? gy - first : GM;
+  glds_body<TC, AK, BK_, NST>(smem, g, A, B, Cp, (first + rem % gsz) * BM, (rem / gsz) * BN);
 }
 
 // Two independent products of the same layout in one launch (unbatched): workgroups [0, nb0)
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(NT256, 1) void gemm_glds256_kernel(GemmArgs g) {
   // of 2 x 16 (18): fewer panel fetches from beyond that XCD's L2 (fabric reads of the fill-pass W1
   // product measured 4.6x its operand bytes with the row-major order).
   const int gx = gridDim.x, gy = gridDim.y;
-  const int GM = gx > 4 ? 8 : 1;  // (a tile row of four or fewer tiles is already a compact patch)
+  const int GM = gx > 4 ? g.group_m : 1;  // (a tile row of four or fewer tiles is already a compact patch)
   const int grp = txy / (GM * gx), first = grp * GM, rem = txy - grp * GM * gx;
   const int gsz = gy - first < GM ? gy - first : GM;
   const int bm = (first + rem % gsz) * 256, bn = (rem / gsz) * 256;
@@ -1120,6 +1127,7 @@ int g_gemm_wide = 1;  // 1 = 256x256 tiles for large-N products with enough tile
 int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte accesses only)
 int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
+int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1135,6 +1143,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
+  if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   return PG_ERR_ARG;
 }
 
@@ -1239,6 +1248,7 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
   a.aux2 = d->act == PG_ACT_MUL_DGELU ? d->aux2 : nullptr;
   a.act = d->act;
   a.A2 = nullptr; a.B2 = nullptr; a.K2 = 0;
+  a.group_m = g_gemm_group_m;
   if (d->K2 > 0) {
     if (!d->A2 || !d->B2 || d->batch != 1) return PG_ERR_ARG;
     if (((uintptr_t)d->A2 | (uintptr_t)d->B2) & 15) return PG_ERR_ALIGN;
