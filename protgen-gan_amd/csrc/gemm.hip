@@ -1128,6 +1128,7 @@ int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte 
 int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
+int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1143,6 +1144,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
+  if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   return PG_ERR_ARG;
 }
@@ -1151,6 +1153,17 @@ namespace {
 int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a);
 ProfEntry* prof_begin(int variant, double flops, hipStream_t st);
 }  // namespace
+
+static int device_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
 
 static long tiles256(const pg_gemm_desc* d) { return (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch; }
 
@@ -1178,6 +1191,28 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
     if (rc1 != PG_OK) return rc1;
     one.A = d->A2; one.B = d->B2; one.K = d->K2; one.beta = 1.f;
     return pg_gemm(&one, stream);
+  }
+  if (wide && g_gemm_wide == 1 && g_gemm_split_tail && d->batch == 1 && d->a_kmajor) {
+    // One 256x256 tile per CU and round: when the last round would be under 30 % full, the rows
+    // beyond the last full round go to a second launch (which takes the 128x128 kernel) instead
+    // of costing a whole round.
+    const int cus = device_cus();
+    const long tiles = tiles256(d), full = tiles / cus;
+    const int gxw = (d->N + 255) / 256;
+    const long rows1 = full * cus / gxw * 256;  // whole tile rows inside the full rounds
+    if (full >= 1 && tiles % cus != 0 && (tiles % cus) * 10 < 3 * (long)cus && rows1 > 0 && rows1 < d->M) {
+      const int esz = 2, csz = d->c_dtype == PG_F32 ? 4 : 2;
+      pg_gemm_desc top = *d, rest = *d;
+      top.M = (int)rows1;
+      rest.M = d->M - (int)rows1;
+      rest.A = (const char*)d->A + rows1 * d->lda * esz;
+      rest.C = (char*)d->C + rows1 * d->ldc * csz;
+      if (d->residual) rest.residual = (const char*)d->residual + rows1 * d->ldr * esz;
+      if (d->aux) rest.aux = (char*)d->aux + rows1 * d->ldaux * esz;
+      if (d->aux2) rest.aux2 = (char*)d->aux2 + rows1 * d->ldaux * esz;
+      const int rc1 = pg_gemm(&top, stream);
+      return rc1 != PG_OK ? rc1 : pg_gemm(&rest, stream);
+    }
   }
   ProfEntry* pe = prof_begin((d->dtype == PG_BF16 ? 8 : 0) + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0),
                              2.0 * d->M * d->N * ((double)d->K + d->K2) * d->batch, st);

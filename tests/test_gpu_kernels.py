@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 from oracle import protbert_cpu as O  # noqa: E402
 from tests import kernel_specs as K  # noqa: E402
 
+K_gelu = K.gelu
+
 
 @pytest.fixture(scope="module")
 def pg():
@@ -212,6 +214,33 @@ def test_gemm_two_reduction_segments(pg, dtype, T, T2):
     with pytest.raises(pg._lib.PgError):  # an epilogue cannot be split over two launches
         pg.ops.gemm(d(dY)[:, :56].contiguous(), d(X)[:, :56].contiguous(), None, a_kmajor=False, b_kmajor=False,
                     bias=torch.zeros(56, device=DEV), A2=d(dYb)[:, :56].contiguous(), B2=d(Xb)[:, :56].contiguous())
+
+
+def test_gemm_wide_tile_split_last_round(pg):
+    """A large-N product whose 256x256 tiles fill the CUs once plus a few: the rows past the last
+    full round of tiles go to a second launch.  Exact integers plus every row-offset epilogue
+    operand (residual, stored pre-activation) across the seam."""
+    g = torch.Generator().manual_seed(41)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N, K = 2048, 128
+    M = (cus // 8 + 1) * 256 + 40  # one full round of tiles, then one and a bit tile rows
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[:, 0] += torch.arange(M) % 5
+    B[:, 1] -= torch.arange(N) % 7
+    ref = A.double() @ B.double().T
+    bf = torch.bfloat16
+    Ad, Bd = A.to(bf).to(DEV), B.to(bf).to(DEV)
+    out = pg.ops.gemm(Ad, Bd, out_dtype=torch.float32)
+    assert torch.equal(out.cpu().double(), ref)
+    res = torch.randint(-8, 9, (M, N), generator=g).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float()
+    aux = torch.empty(M, N, dtype=bf, device=DEV)
+    out = pg.ops.gemm(Ad, Bd, alpha=1.0 / 64, bias=bias.to(DEV), residual=res.to(bf).to(DEV))
+    close(out, ref / 64 + bias.double() + res.double(), bf)
+    out = pg.ops.gemm(Ad, Bd, alpha=1.0 / 64, bias=bias.to(DEV), act=pg._lib.PG_ACT_GELU, aux=aux)
+    close(aux, ref / 64 + bias.double(), bf)
+    close(out, K_gelu(ref / 64 + bias.double()), bf)
 
 
 def test_gemm_rejects_bad_arguments(pg):
