@@ -1129,6 +1129,7 @@ int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after th
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
 int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
+int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1144,6 +1145,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
+  if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   return PG_ERR_ARG;
@@ -1181,7 +1183,7 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
                      // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
                      // traffic outweighs the partial last round
-                     (g_gemm_wide == 1 && d->N >= 512 && d->K >= 2048 && tiles256(d) >= 512));
+                     (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= 512));
   if (d->K2 > 0 && (!fast || narrow || wide || !g_gemm_dualk)) {
     // only the 128x128 direct-to-LDS kernel walks two reduction segments: elsewhere two launches
     if (d->bias || d->residual || d->act != PG_ACT_NONE) return PG_ERR_UNSUPPORTED;  // the epilogue would apply twice
