@@ -322,35 +322,45 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
   const int m0 = m_base + (lane & 15);
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
   const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
+  // this lane's two column groups (jh = 0, 2) and their biases
+  int nn[2];
+  float bv[2][8];
 #pragma unroll
-  for (int jh = 0; jh < 4; jh += 2) {
-    const int nn = n_base + (jh + (gq & 1)) * 16 + 8 * (gq >> 1);
-    float bv[8];
+  for (int h = 0; h < 2; ++h) {
+    nn[h] = n_base + (2 * h + (gq & 1)) * 16 + 8 * (gq >> 1);
     if (g.bias) {
-      VecIO<float, 4>::load(g.bias + nn, bv);
-      VecIO<float, 4>::load(g.bias + nn + 4, bv + 4);
+      VecIO<float, 4>::load(g.bias + nn[h], bv[h]);
+      VecIO<float, 4>::load(g.bias + nn[h] + 4, bv[h] + 4);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      for (int e = 0; e < 8; ++e) bv[h][e] = 0.f;
     }
+  }
+  // Row block outermost: the two 64-byte halves of every 128-byte output line leave in consecutive
+  // store instructions.  (Column group outermost put eight stores between them, and fabric-side
+  // write bytes of a 4096-wide output measured 1.4x the output size: lines written back half full,
+  // then again.)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const long m = m0 + i * 16;
+  for (int i = 0; i < MI; ++i) {
+    const long m = m0 + i * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int jh = 2 * h;
       float v[8], u[8], r[8];
-      if (g.act == PG_ACT_MUL_DGELU) VecIO<bf16_t, 8>::load(aux + m * g.ldaux + nn, u);
-      if (res) VecIO<bf16_t, 8>::load(res + m * g.ldr + nn, r);
+      if (g.act == PG_ACT_MUL_DGELU) VecIO<bf16_t, 8>::load(aux + m * g.ldaux + nn[h], u);
+      if (res) VecIO<bf16_t, 8>::load(res + m * g.ldr + nn[h], r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][jh][e]), __float_as_uint(acc[i][jh + 1][e]), false, false);
-        v[e] = __uint_as_float(sw[0]) * g.alpha + bv[e];
-        v[4 + e] = __uint_as_float(sw[1]) * g.alpha + bv[4 + e];
+        v[e] = __uint_as_float(sw[0]) * g.alpha + bv[h][e];
+        v[4 + e] = __uint_as_float(sw[1]) * g.alpha + bv[h][4 + e];
       }
       if (g.act == PG_ACT_GELU) {
-        if (g.aux) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux) + m * g.ldaux + nn, v);
+        if (g.aux) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux) + m * g.ldaux + nn[h], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
       } else if (g.act == PG_ACT_MUL_DGELU) {
-        if (g.aux2) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux2) + m * g.ldaux + nn, v);
+        if (g.aux2) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux2) + m * g.ldaux + nn[h], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_d1_fast(u[e]);
       }
@@ -360,11 +370,11 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
       }
       if (g.beta != 0.f) {
         float c0[8];
-        VecIO<bf16_t, 8>::load(Cp + m * g.ldc + nn, c0);
+        VecIO<bf16_t, 8>::load(Cp + m * g.ldc + nn[h], c0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
       }
-      VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn, v);
+      VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
     }
   }
 }
