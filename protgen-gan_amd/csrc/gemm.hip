@@ -1188,7 +1188,8 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && d->K2 % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
                     (d->b_kmajor || d->N >= 8);
   const long blocks128 = (long)grid.x * grid.y * grid.z;
-  const bool narrow = fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256));
+  const bool narrow = fast && d->K2 == 0 && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256) ||
+                              (g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
                      // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
