@@ -63,6 +63,7 @@ SIGNATURES = {
     "pg_head_offset": (i64, [i32, i32, i32]),
     "pg_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "pg_gemm_pair": (i32, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), vp]),
+    "pg_gemm_group": (i32, [C.POINTER(GemmDesc), i32, vp]),
     "pg_tune": (i32, [i32, i32]),
     "pg_profile_begin": (i32, [i32]),
     "pg_profile_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

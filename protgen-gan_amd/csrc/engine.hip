@@ -382,7 +382,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     CK(pg_layernorm_bwd(dtype, s.f, dy, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, a.f,
                         grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
                         grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
-    if (grads) CK(g.run(a.f, false, H, s.gu, false, I, pv.g(pv.lo(l, PG_L_W2)), PG_F32, I, H, I, T, 1.f, 1.f));
+    // (the four weight gradients of the layer are launched together once dqkv exists: see below)
     // d gu = df W2 ; du = dgu * gelu'(u)
     if (save) {
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.gu, dtype, I, T, I, H, 1.f, 0.f));
@@ -391,10 +391,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.u, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
                PG_ACT_MUL_DGELU, s.u, I));
     }
-    if (grads) {
-      CK(g.run(a.u, false, I, s.h, false, H, pv.g(pv.lo(l, PG_L_W1)), PG_F32, H, I, H, T, 1.f, 1.f));
-      CK(pg_colsum_acc(dtype, a.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
-    }
+    if (grads) CK(pg_colsum_acc(dtype, a.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
     // dh = du W1 + df
     CK(g.run(a.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, a.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, a.f, H));
     // LN1
@@ -418,8 +415,12 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              0.f));
     if (grads) {
-      CK(g.dw_pair(g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T),
-                   g.dw_desc(a.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T)));
+      // dW2 = df^T gu, dW1 = du^T h, dWqkv = dqkv^T x, dWo = da^T ctx: 64 + 64 + 48 + 16 tiles of 256x256
+      const pg_gemm_desc dws[4] = {g.dw_desc(a.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T),
+                                   g.dw_desc(a.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T),
+                                   g.dw_desc(a.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T),
+                                   g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T)};
+      CK(pg_gemm_group(dws, 4, st));
       CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // dx = dqkv Wqkv + da
@@ -513,16 +514,11 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, w.f,
                          grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
                          grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
-    if (grads) {
-      CK(g.dw(g.dw_desc(w.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu)));  // W2bar = fbar^T gu + gf^T gudot
-    }
+    // (W2bar = fbar^T gu + gf^T gudot and the other three weight gradients: one grouped launch at the end of the layer)
     // gubar = fbar W2 ; ubar = gelu'(u) gubar + gelu''(u) udot ggu
     CK(g.run(w.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
     CK(pg_gelu_bwd2(dtype, s.u, t.u, a.gu, w.gu, w.u, (int64_t)d.T * I, st));
-    if (grads) {
-      CK(g.dw(g.dw_desc(w.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h)));
-      CK(pg_colsum_acc(dtype, w.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
-    }
+    if (grads) CK(pg_colsum_acc(dtype, w.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
     // hbar = ubar W1 + fbar
     CK(g.run(w.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, w.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, w.f, H));
     // LN1: abar
@@ -559,8 +555,11 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              1.f));
     if (grads) {
-      CK(g.dw_pair(g.dw_desc(w.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx),
-                   g.dw_desc(w.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T, a.qkv, t.x)));
+      const pg_gemm_desc dws[4] = {g.dw_desc(w.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu),
+                                   g.dw_desc(w.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h),
+                                   g.dw_desc(w.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T, a.qkv, t.x),
+                                   g.dw_desc(w.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx)};
+      CK(pg_gemm_group(dws, 4, st));
       CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
     }
     // xbar = qkvbar Wqkv + abar

@@ -893,10 +893,12 @@ __device__ __forceinline__ void glds256_tile(unsigned a_addr, unsigned b_addr, c
 }
 
 template <bool AK, bool BK_, int PH, int DBG>
-__device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t* A, const bf16_t* B, int bm, int bn, bf16_t* smem,
-                                                 int wid, int lane, f32x4 (&acc)[8][4]) {
+__device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t* A, const bf16_t* B, const bf16_t* A2,
+                                                 const bf16_t* B2, int bm, int bn, bf16_t* smem, int wid, int lane,
+                                                 f32x4 (&acc)[8][4]) {
   const int wr = wid >> 2, wc = wid & 3, w4 = wid & 3, half = wid >> 2;
-  const int nt = g.K / GBK;
+  // k-tiles [0, nt1) come from (A, B), k-tiles [nt1, nt) from the optional second segment (A2, B2)
+  const int nt1 = g.K / GBK, nt = nt1 + g.K2 / GBK;
   const FragOff<AK> fa_lo = frag_offsets<AK>(0, lane), fa_hi = frag_offsets<AK>(1, lane);
   const FragOff<BK_> fb = frag_offsets<BK_>(wc & 1, lane);
   const unsigned smem_addr = lds_addr(smem);
@@ -918,8 +920,13 @@ __device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t
   for (int t = 0; t < nt - 1; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile t landed for every wave; the other stage is no longer being read
-    a_src += a_step;
-    b_src += b_step;
+    if (t + 1 == nt1) {  // the next k-tile opens the second segment
+      a_src = reinterpret_cast<const char*>(AK ? A2 + (long)bm * g.lda : A2 + bm);
+      b_src = reinterpret_cast<const char*>(BK_ ? B2 + (long)bn * g.ldb : B2 + bn);
+    } else {
+      a_src += a_step;
+      b_src += b_step;
+    }
     const unsigned st = smem_addr + (t & 1) * 8 * GT_ELEMS;
     bf16_t* nx = smem + ((t + 1) & 1) * 4 * GT_ELEMS + dst0;
     glds256_tile<AK, BK_, PH, !(DBG & 1), !(DBG & 2)>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc, a_src, b_src, aoff, boff, nx,
@@ -929,6 +936,36 @@ __device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t
   __builtin_amdgcn_s_barrier();
   const unsigned st = smem_addr + ((nt - 1) & 1) * 8 * GT_ELEMS;
   glds256_tile<AK, BK_, PH, false, !(DBG & 2)>(st + a_off, st + b_off, fa_lo, fa_hi, fb, acc, a_src, b_src, aoff, boff, smem, smem);
+}
+
+// One 256 x 256 output tile: tile index txy inside a gx x gy grid of tiles.  Tile order: groups of
+// eight tile rows, walked down the rows first.  The ~32 workgroups an XCD runs at a time then cover
+// about 8 x 4 tiles (12 distinct operand panels) instead of 2 x 16 (18): fewer panel fetches from
+// beyond that XCD's L2 (fabric reads of the fill-pass W1 product measured 4.6x its operand bytes
+// with the row-major order).
+template <typename TC, bool AK, bool BK_, int DBG>
+__device__ __forceinline__ void glds256_block(const GemmArgs& g, const bf16_t* A, const bf16_t* B, TC* Cp, int txy, int gx, int gy,
+                                              bf16_t* smem) {
+  const int GM = gx > 4 ? g.group_m : 1;  // (a tile row of four or fewer tiles is already a compact patch)
+  const int grp = txy / (GM * gx), first = grp * GM, rem = txy - grp * GM * gx;
+  const int gsz = gy - first < GM ? gy - first : GM;
+  const int bm = (first + rem % gsz) * 256, bn = (rem / gsz) * 256;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const bf16_t* A2 = reinterpret_cast<const bf16_t*>(g.A2);
+  const bf16_t* B2 = reinterpret_cast<const bf16_t*>(g.B2);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // waves w and w + 4 share a SIMD: opposite piece phases
+  if (wr == 0) glds256_mainloop<AK, BK_, 0, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
+  else glds256_mainloop<AK, BK_, 1, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
+  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
 }
 
 template <typename TC, bool AK, bool BK_, int DBG = 0>
@@ -941,29 +978,35 @@ __global__ __launch_bounds__(NT256, 1) void gemm_glds256_kernel(GemmArgs g) {
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
   TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
-  // Tile order inside a batch entry: groups of eight tile rows, walked down the rows first.  The ~32
-  // workgroups an XCD runs at a time then cover about 8 x 4 tiles (12 distinct operand panels) instead
-  // of 2 x 16 (18): fewer panel fetches from beyond that XCD's L2 (fabric reads of the fill-pass W1
-  // product measured 4.6x its operand bytes with the row-major order).
-  const int gx = gridDim.x, gy = gridDim.y;
-  const int GM = gx > 4 ? g.group_m : 1;  // (a tile row of four or fewer tiles is already a compact patch)
-  const int grp = txy / (GM * gx), first = grp * GM, rem = txy - grp * GM * gx;
-  const int gsz = gy - first < GM ? gy - first : GM;
-  const int bm = (first + rem % gsz) * 256, bn = (rem / gsz) * 256;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
+  glds256_block<TC, AK, BK_, DBG>(g, A, B, Cp, txy, gridDim.x, gridDim.y, smem);
+}
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+// Up to four unbatched products of one layout in one launch of 256x256 tiles: workgroups
+// [first[i], first[i+1]) tile product i.  The four weight gradients of a transformer layer have
+// 64 + 64 + 48 + 16 such tiles: none covers the chip alone, together they nearly do, at twice the
+// operand reuse of 128x128 tiles.
+struct GemmArgsG { GemmArgs p[4]; int first[5]; int gx[4]; int gy[4]; };
 
-  // waves w and w + 4 share a SIMD: opposite piece phases
-  if (wr == 0) glds256_mainloop<AK, BK_, 0, DBG>(g, A, B, bm, bn, smem, wid, lane, acc);
-  else glds256_mainloop<AK, BK_, 1, DBG>(g, A, B, bm, bn, smem, wid, lane, acc);
-  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
+template <typename TC, bool AK, bool BK_>
+__global__ __launch_bounds__(NT256, 1) void gemm_glds256_group_kernel(GemmArgsG a) {
+  __shared__ __align__(16) bf16_t smem[2 * 4 * GT_ELEMS];
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int i = 0;
+  if (lid >= a.first[1]) i = 1;
+  if (lid >= a.first[2]) i = 2;
+  if (lid >= a.first[3]) i = 3;
+  const GemmArgs& g = a.p[i];
+  glds256_block<TC, AK, BK_, 0>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
+                                reinterpret_cast<TC*>(g.C), lid - a.first[i], a.gx[i], a.gy[i], smem);
+}
+
+template <typename TC>
+int launch_glds256_group(const pg_gemm_desc* d, const GemmArgsG& a, int blocks, hipStream_t st) {
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_group_kernel<TC, true, true>), dim3(blocks), dim3(NT256), 0, st, a);
+  else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_group_kernel<TC, true, false>), dim3(blocks), dim3(NT256), 0, st, a);
+  else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_group_kernel<TC, false, true>), dim3(blocks), dim3(NT256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_glds256_group_kernel<TC, false, false>), dim3(blocks), dim3(NT256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
 template <typename TC>
@@ -1140,6 +1183,7 @@ int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
 int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
+int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1155,6 +1199,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
+  if (key == 11) { g_gemm_group = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
@@ -1195,8 +1240,8 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
                      // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
                      // traffic outweighs the partial last round
                      (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= 512));
-  if (d->K2 > 0 && (!fast || narrow || wide || !g_gemm_dualk)) {
-    // only the 128x128 direct-to-LDS kernel walks two reduction segments: elsewhere two launches
+  if (d->K2 > 0 && (!fast || narrow || !g_gemm_dualk)) {
+    // only the 128x128 and 256x256 direct-to-LDS kernels walk two reduction segments: elsewhere two launches
     if (d->bias || d->residual || d->act != PG_ACT_NONE) return PG_ERR_UNSUPPORTED;  // the epilogue would apply twice
     pg_gemm_desc one = *d;
     one.K2 = 0; one.A2 = nullptr; one.B2 = nullptr;
@@ -1355,6 +1400,46 @@ extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void
   const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && kmin >= 4 * GBK);
   if (deep) rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 4>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 4>(d0, a, blocks, st);
   else rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 2>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 2>(d0, a, blocks, st);
+  if (pe) hipEventRecord(pe->b, st);
+  return rc;
+}
+
+extern "C" int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream) {
+  if (!d || n < 1 || n > 4) return PG_ERR_ARG;
+  GemmArgsG a;
+  bool together = g_gemm_path != 0 && g_gemm_group != 0 && n >= 2;
+  long tiles = 0;
+  double flops = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = gemm_prepare(&d[i], a.p[i]);
+    if (rc != PG_OK) return rc;
+    const pg_gemm_desc* di = &d[i];
+    together = together && di->dtype == PG_BF16 && di->K % GBK == 0 && di->K2 % GBK == 0 && di->batch == 1 && di->N > 64 &&
+               (di->a_kmajor || di->M >= 8) && (di->b_kmajor || di->N >= 8) && di->a_kmajor == d[0].a_kmajor &&
+               di->b_kmajor == d[0].b_kmajor && di->c_dtype == d[0].c_dtype && (di->K2 == 0 || g_gemm_dualk != 0);
+    a.gx[i] = (di->N + 255) / 256;
+    a.gy[i] = (di->M + 255) / 256;
+    a.first[i] = (int)tiles;
+    tiles += (long)a.gx[i] * a.gy[i];
+    flops += 2.0 * di->M * di->N * ((double)di->K + di->K2);
+  }
+  for (int i = n; i < 4; ++i) { a.p[i] = a.p[0]; a.gx[i] = a.gy[i] = 1; a.first[i] = 0x7fffffff; }
+  a.first[4] = 0x7fffffff;
+  // worth it only if the 256x256 tiles of all products together occupy most of the chip
+  const int cus = device_cus();
+  together = together && tiles * 2 >= cus && tiles <= 0x7fffffff / 2;
+  if (!together) {
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+      const int rc = pg_gemm_pair(&d[i], &d[i + 1], stream);
+      if (rc != PG_OK) return rc;
+    }
+    return i < n ? pg_gemm(&d[i], stream) : PG_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ProfEntry* pe = prof_begin(8 + (d[0].c_dtype == PG_F32 ? 4 : 0) + (d[0].a_kmajor ? 2 : 0) + (d[0].b_kmajor ? 1 : 0), flops, st);
+  const int rc = d[0].c_dtype == PG_F32 ? launch_glds256_group<float>(&d[0], a, (int)tiles, st)
+                                        : launch_glds256_group<bf16_t>(&d[0], a, (int)tiles, st);
   if (pe) hipEventRecord(pe->b, st);
   return rc;
 }

@@ -61,6 +61,28 @@ def gemm_pair(A0, B0, C0, A1, B1, C1, *, a_kmajor=True, b_kmajor=True, alpha=1.0
     return C0, C1
 
 
+def gemm_group(problems, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0):
+    """Up to four 2-D GEMMs of one layout in one launch (pg_gemm_group).  `problems` is a list of
+    (A, B, C) or (A, B, C, A2, B2) tuples; outputs must be given."""
+    assert 1 <= len(problems) <= 4
+    arr = (_lib.GemmDesc * len(problems))()
+    for i, pr in enumerate(problems):
+        A, B, Cm = pr[:3]
+        _need_cuda(A, B)
+        M, K = (A.shape if a_kmajor else (A.shape[1], A.shape[0]))
+        N, K2 = (B.shape if b_kmajor else (B.shape[1], B.shape[0]))
+        assert K == K2 and A.stride(1) == 1 and B.stride(1) == 1 and Cm.shape == (M, N)
+        d = _plain_desc(A, B, Cm, a_kmajor, b_kmajor, M, N, K, alpha, beta)
+        if len(pr) == 5:
+            A2, B2 = pr[3], pr[4]
+            assert A2.stride(0) == A.stride(0) and B2.stride(0) == B.stride(0)
+            d.A2, d.B2 = A2.data_ptr(), B2.data_ptr()
+            d.K2 = A2.shape[1] if a_kmajor else A2.shape[0]
+        arr[i] = d
+    check(lib.pg_gemm_group(arr, len(problems), stream()), "pg_gemm_group")
+    return [pr[2] for pr in problems]
+
+
 def gemm(A, B, C_out=None, *, a_kmajor=True, b_kmajor=True, out_dtype=None, alpha=1.0, beta=0.0, bias=None,
          residual=None, act=PG_ACT_NONE, aux=None, aux2=None, A2=None, B2=None):
     """2-D GEMM.  A is [M,K] (a_kmajor) or [K,M]; B is [N,K] (b_kmajor) or [K,N].  (A2, B2): an

@@ -211,9 +211,14 @@ def test_gemm_two_reduction_segments(pg, dtype, T, T2):
     c = C0.clone().to(DEV)
     pg.ops.gemm(d(dY), d(X), c, a_kmajor=False, b_kmajor=False, beta=1.0, A2=d(dYb), B2=d(Xb))
     close(c, C0.double() + dY.double().T @ X.double() + dYb.double().T @ Xb.double(), dtype)
-    with pytest.raises(pg._lib.PgError):  # an epilogue cannot be split over two launches
-        pg.ops.gemm(d(dY)[:, :56].contiguous(), d(X)[:, :56].contiguous(), None, a_kmajor=False, b_kmajor=False,
-                    bias=torch.zeros(56, device=DEV), A2=d(dYb)[:, :56].contiguous(), B2=d(Xb)[:, :56].contiguous())
+    args = dict(a_kmajor=False, b_kmajor=False, bias=torch.ones(56, device=DEV), A2=d(dYb)[:, :56].contiguous(),
+                B2=d(Xb)[:, :56].contiguous())
+    if dtype == torch.float32 or T % 64 or T2 % 64:
+        with pytest.raises(pg._lib.PgError):  # two launches: an epilogue cannot be split over them
+            pg.ops.gemm(d(dY)[:, :56].contiguous(), d(X)[:, :56].contiguous(), None, **args)
+    else:  # one launch walks both segments, so a bias is fine
+        out = pg.ops.gemm(d(dY)[:, :56].contiguous(), d(X)[:, :56].contiguous(), None, out_dtype=torch.float32, **args)
+        close(out, dY[:, :56].double().T @ X[:, :56].double() + dYb[:, :56].double().T @ Xb[:, :56].double() + 1.0, dtype)
 
 
 def test_gemm_wide_tile_split_last_round(pg):
@@ -241,6 +246,36 @@ def test_gemm_wide_tile_split_last_round(pg):
     out = pg.ops.gemm(Ad, Bd, alpha=1.0 / 64, bias=bias.to(DEV), act=pg._lib.PG_ACT_GELU, aux=aux)
     close(aux, ref / 64 + bias.double(), bf)
     close(out, K_gelu(ref / 64 + bias.double()), bf)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [128, 200])
+def test_gemm_group_weight_gradients(pg, dtype, T):
+    """pg_gemm_group: four accumulating weight-gradient products of different shapes (enough
+    256x256 tiles between them to take the grouped kernel in bf16 when T is whole k-tiles), two of
+    them with a second reduction segment, against one pg_gemm per product."""
+    g = torch.Generator().manual_seed(33)
+    shapes = [(2056, 2296), (2296, 2056), (1536, 520), (520, 520)]  # 81 + 81 + 18 + 9 tiles of 256x256
+    d = lambda t: t.to(dtype).to(DEV)  # noqa: E731
+    probs, refs, singles = [], [], []
+    for i, (No, Ni) in enumerate(shapes):
+        dY, X = rnd(T, No, dtype=dtype, gen=g), rnd(T, Ni, dtype=dtype, gen=g)
+        C0 = torch.randn(No, Ni, generator=g)
+        ref = C0.double() + dY.double().T @ X.double()
+        pr = [d(dY), d(X), C0.clone().to(DEV)]
+        if i % 2 == 0:
+            dYb, Xb = rnd(64, No, dtype=dtype, gen=g), rnd(64, Ni, dtype=dtype, gen=g)
+            ref = ref + dYb.double().T @ Xb.double()
+            pr += [d(dYb), d(Xb)]
+        probs.append(tuple(pr))
+        refs.append(ref)
+        e = C0.clone().to(DEV)
+        pg.ops.gemm(pr[0], pr[1], e, a_kmajor=False, b_kmajor=False, beta=1.0, **({"A2": pr[3], "B2": pr[4]} if len(pr) == 5 else {}))
+        singles.append(e)
+    outs = pg.ops.gemm_group(probs, a_kmajor=False, b_kmajor=False, alpha=1.0, beta=1.0)
+    for o, r, e in zip(outs, refs, singles):
+        close(o, r, dtype)
+        assert torch.equal(o, e)
 
 
 def test_gemm_rejects_bad_arguments(pg):
