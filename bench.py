@@ -111,8 +111,15 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    verbose = os.environ.get("PG_BENCH_VERBOSE") == "1"
+    if verbose:
+        import faulthandler
+        faulthandler.dump_traceback_later(60, repeat=False, file=sys.stderr)
     for i in range(args.warmup):
         one_step(i)
+        if verbose:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] warm-up step {i} done", file=sys.stderr, flush=True)
     fence()
     generator.fill_shapes.clear()
     lib.pg_profile_begin(args.profile_sample)
@@ -126,7 +133,7 @@ def main():
     nl = ctypes.c_int64(0)
     lib.pg_profile_end(prof, ctypes.byref(nl))
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     c_loss, g_loss = float(last[0]), float(last[1])

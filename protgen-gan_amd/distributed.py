@@ -25,11 +25,18 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # PG_REHEARSE_ONE_GPU=1: every rank on device 0 over gloo, to exercise the multi-rank code path
+        # on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
+        rehearse = os.environ.get("PG_REHEARSE_ONE_GPU") == "1"
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.is_available() and not rehearse else "gloo"
+        if rehearse:
+            local = 0
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif os.environ.get("PG_REHEARSE_ONE_GPU") == "1":
+        local = 0
     return rank, local, world
 
 
@@ -84,8 +91,12 @@ class GradSync:
                 continue
             for a, b in bucket_ranges(live_ranges(store), self.bucket_elems):
                 chunk = store.grad[a:b]
-                if chunk.is_cuda:
+                if chunk.is_cuda and dist.get_backend() == "nccl":
                     works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+                elif chunk.is_cuda:  # gloo (rehearsal only): stage through the host, it has no AVG either
+                    host = chunk.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    chunk.copy_(host.div_(self.world))
                 else:
                     dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
                     chunk.div_(self.world)

@@ -286,6 +286,47 @@ def test_train_critic_update_matches_oracle(pg):
         rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
 
 
+def test_grad_sync_over_rccl_one_rank(pg, tmp_path):
+    """GradSync's RCCL branch (asynchronous AVG all-reduce of slices of the flat gradient buffer, issued
+    behind the backward kernels on the current stream) on a process group of one rank: averaging over
+    one rank must leave every gradient as the unsynchronised update computes it."""
+    import torch.distributed as dist
+    from protgen_gan_amd import train as T
+    from protgen_gan_amd.distributed import GradSync
+    c, P, PC, C, _, critic = build(pg, "tiny", torch.float32)
+    g = torch.Generator().manual_seed(79)
+    B, S = 2, 24
+    real = torch.randint(5, 25, (B, S), generator=g).to(DEV)
+    fake = torch.randint(5, 25, (B, S), generator=g).to(DEV)
+    rm = torch.ones(B, S, device=DEV)
+    alpha = torch.rand(B, 1, 1, generator=g).to(DEV)
+
+    class NoStep:
+        def zero_grad(self):
+            critic.zero_grad(set_to_none=True)
+
+        def step(self):
+            pass
+
+    T.critic_update(critic, NoStep(), real, rm, fake, T.GanHyper(lambda_gp=5.0), alpha=alpha)
+    want = {n: p.grad.clone() for n, p in critic.named_parameters() if p.grad is not None}
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        sync = GradSync([critic.protbert.store, critic.classifier.store], world=2, bucket_bytes=1 << 16)
+        T.critic_update(critic, NoStep(), real, rm, fake, T.GanHyper(lambda_gp=5.0), grad_sync=sync, alpha=alpha)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    got = {n: p.grad for n, p in critic.named_parameters() if p.grad is not None}
+    assert got.keys() == want.keys() and len(got) > 10
+    for n in want:
+        # atomically accumulated bias gradients may differ in summation order between two runs
+        err = float((got[n] - want[n]).abs().max())
+        assert err <= 1e-5 * float(want[n].abs().max()) + 1e-9, (n, err)
+
+
 def _blind_template(lengths, width):
     ids = torch.full((len(lengths), width), O.PAD, dtype=torch.long)
     for i, L in enumerate(lengths):
