@@ -87,7 +87,8 @@ def main():
     hp = pgt.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.seq, gen_batch_blind=args.gen_batch)
     gen_opt = pg.AdamW(generator.parameters(), lr=5e-6, betas=(0.9, 0.999), weight_decay=0.01)
     critic_opt = pg.AdamW(critic.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
-    sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world)
+    sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world, overlap=critic.protbert,
+                        position_rows=args.seq)
 
     rng = random.Random(1234 + rank)
     torch.manual_seed(1234 + rank)
@@ -102,9 +103,19 @@ def main():
     real = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic)]
             for _ in range(total)]
 
+    use_sync = world > 1
+    if world == 1 and os.environ.get("PG_REHEARSE_SYNC") == "1":
+        # one-rank RCCL group: the host and stream cost of the layer-wise gradient reduction, nothing to reduce with
+        import tempfile
+        torch.distributed.init_process_group("nccl", init_method=f"file://{tempfile.mkdtemp()}/rdv", rank=0, world_size=1,
+                                             device_id=dev)
+        sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], 2, overlap=critic.protbert,
+                            position_rows=args.seq)
+        use_sync = True
+
     def one_step(i):
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
-                                  grad_sync=sync if world > 1 else None)
+                                  grad_sync=sync if use_sync else None)
 
     def fence():
         if world > 1:
@@ -183,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -287,12 +287,17 @@ int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const 
  * flags: bit0 = accumulate parameter gradients into p->grad; bit1 = write every layer's
  * adjoints into adj_stash (same layout as the forward stash; needed by the GP).
  * dx_out (nullable) receives the gradient w.r.t. the encoder input (the embedding output;
- * its own backward is pg_layernorm_bwd + pg_embed_scatter).                              */
+ * its own backward is pg_layernorm_bwd + pg_embed_scatter).
+ * layer_done (nullable; also on pg_encoder_backward2): cfg->layers hipEvent_t handles.  With bit0 set,
+ * event l is recorded on `stream` once every launch that adds into layer l's parameter gradients
+ * has been issued (layers finish from the last to the first), so that a data-parallel caller can
+ * start reducing a layer's gradients on another stream while the pass goes on.  The reference
+ * trains on one GPU and has no counterpart.                                               */
 #define PG_BWD_PARAM_GRADS 1
 #define PG_BWD_SAVE_ADJOINTS 2
 int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                         void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
-                        void* workspace, int64_t workspace_bytes, void* stream);
+                        void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done);
 /* GP tangent-forward pass: xdot_in [B,S,H] -> hdot_out [B,S,H]; writes the tangent stash. */
 int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                    const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
@@ -302,7 +307,7 @@ int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B
  * pg_gp_direction) and writes the gradient w.r.t. the encoder input x to xbar_out (nullable). */
 int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                          const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
-                         void* workspace, int64_t workspace_bytes, void* stream);
+                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done);
 
 #ifdef __cplusplus
 }

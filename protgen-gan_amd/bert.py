@@ -97,6 +97,9 @@ class FlatStore:
         self.adam_m = None
         self.adam_v = None
         self.adam_step = 0
+        # offset -> leading elements of that view a backward may write (set by a data-parallel caller that
+        # promises a bound, e.g. the rows of the position table within the padded width)
+        self.live_elems: Dict[int, int] = {}
 
     def shadow_ptr(self):
         v = self.master._version
@@ -332,7 +335,36 @@ class ProtBertForMaskedLM(nn.Module):
             for suffix, which in _LAYER_NAMES:
                 self._add_param(f"bert.encoder.layer.{l}.{suffix}",
                                 lib.pg_param_offset_layer(C.byref(self._ccfg), l, which), reachable=True)
+        self._layer_events = None
+        self._layer_event_arr = None
         self.reset_parameters(seed=None)
+
+    # -- per-layer "gradients issued" events for a data-parallel caller
+    def enable_layer_events(self):
+        """One event per encoder layer; the backward passes record event l on the current stream once
+        layer l's parameter-gradient launches are issued (pg_encoder_backward / pg_encoder_backward2)."""
+        if self._layer_events is None:
+            L = self.config.num_hidden_layers
+            with torch.cuda.device(self.device):
+                evs = [torch.cuda.Event() for _ in range(L)]
+                for e in evs:
+                    e.record()  # the handle exists only after the first record
+            self._layer_events = evs
+            self._layer_event_arr = (C.c_void_p * L)(*[e.cuda_event for e in evs])
+        return self._layer_events
+
+    def layer_param_range(self, l: int):
+        """[lo, hi) of layer l's parameters in the flat store."""
+        pre = f"bert.encoder.layer.{l}."
+        spans = [(off, off + p.numel()) for (name, off), p in
+                 ((kv, self.get_parameter(kv[0])) for kv in self._offsets.items() if kv[0].startswith(pre))]
+        return min(a for a, _ in spans), max(b for _, b in spans)
+
+    def limit_position_rows(self, rows: int):
+        """Promise that no backward sees more than `rows` positions: gradient reductions then skip the
+        rest of the position table (rows nobody writes are zero on every rank)."""
+        off = lib.pg_param_offset_global(C.byref(self._ccfg), _lib.P_POS_EMB)
+        self.store.live_elems[off] = min(rows, self.config.max_position_embeddings) * self.config.hidden_size
 
     # -- construction helpers
     def _add_param(self, name, offset, reachable):
@@ -482,6 +514,9 @@ class ProtBertForMaskedLM(nn.Module):
         """LayerNorm backward of BertEmbeddings, then scatter into the three tables."""
         B, S = ids.shape
         H = self.config.hidden_size
+        bound = self.store.live_elems.get(lib.pg_param_offset_global(C.byref(self._ccfg), _lib.P_POS_EMB))
+        if bound is not None and S * H > bound:
+            raise ValueError(f"{S} positions exceed the bound of {bound // H} given to limit_position_rows")
         dt = ops.dt_code(self.compute_dtype)
         dsum = torch.empty_like(esum)
         part = torch.empty(3 * H * lib.pg_ln_partial_rows(B * S), dtype=torch.float32, device=ids.device)
@@ -521,7 +556,8 @@ class ProtBertForMaskedLM(nn.Module):
         dx = torch.empty_like(dh)
         pr = _params_struct(self.store, self.compute_dtype, param_grads)
         check(lib.pg_encoder_backward(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), dh.data_ptr(), None,
-                                      flags, ops.ptr(adj_stash), dx.data_ptr(), ws.data_ptr(), n, ops.stream()),
+                                      flags, ops.ptr(adj_stash), dx.data_ptr(), ws.data_ptr(), n, ops.stream(),
+                                      self._layer_event_arr if param_grads else None),
               "pg_encoder_backward")
         return dx
 
@@ -540,7 +576,8 @@ class ProtBertForMaskedLM(nn.Module):
         xbar = torch.empty(B, S, self.config.hidden_size, dtype=self.compute_dtype, device=self.device) if want_xbar else None
         pr = _params_struct(self.store, self.compute_dtype, True)
         check(lib.pg_encoder_backward2(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), adj.data_ptr(),
-                                       tan.data_ptr(), PG_BWD_PARAM_GRADS, ops.ptr(xbar), ws.data_ptr(), n, ops.stream()),
+                                       tan.data_ptr(), PG_BWD_PARAM_GRADS, ops.ptr(xbar), ws.data_ptr(), n, ops.stream(),
+                                       self._layer_event_arr),
               "pg_encoder_backward2")
         return xbar
 

@@ -343,7 +343,7 @@ extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dt
 // ------------------------------------------------------------------ first-order backward
 extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                    void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
-                                   void* workspace, int64_t workspace_bytes, void* stream) {
+                                   void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done) {
   (void)mask;
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
@@ -422,6 +422,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
                                    g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T)};
       CK(pg_gemm_group(dws, 4, st));
       CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+      if (layer_done && hipEventRecord((hipEvent_t)layer_done[l], st) != hipSuccess) return PG_ERR_LAUNCH;
     }
     // dx = dqkv Wqkv + da
     CK(g.run(a.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, a.x, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, a.a, H));
@@ -487,7 +488,7 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
 // ------------------------------------------------------------------ GP second-order reverse pass
 extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                     const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
-                                    void* workspace, int64_t workspace_bytes, void* stream) {
+                                    void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done) {
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS;
@@ -561,6 +562,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
                                    g.dw_desc(w.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx)};
       CK(pg_gemm_group(dws, 4, st));
       CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+      if (layer_done && hipEventRecord((hipEvent_t)layer_done[l], st) != hipSuccess) return PG_ERR_LAUNCH;
     }
     // xbar = qkvbar Wqkv + abar
     CK(g.run(w.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, xbar, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, w.a, H));

@@ -60,7 +60,9 @@ def bucket_ranges(ranges: List[Tuple[int, int]], bucket_elems: int) -> List[Tupl
 
 def live_ranges(store) -> List[Tuple[int, int]]:
     """Contiguous ranges of a flat store covered by parameters that currently hold a gradient."""
-    rs = sorted((off, off + n) for p, off, n in store.views if p.requires_grad and p.grad is not None)
+    bound = getattr(store, "live_elems", {})
+    rs = sorted((off, off + min(n, bound.get(off, n))) for p, off, n in store.views
+                if p.requires_grad and p.grad is not None)
     merged: List[List[int]] = []
     for a, b in rs:
         if merged and a <= merged[-1][1] + 8:
@@ -70,38 +72,120 @@ def live_ranges(store) -> List[Tuple[int, int]]:
     return [(a, b) for a, b in merged]
 
 
+def clip_ranges(ranges: List[Tuple[int, int]], lo: int, hi: int) -> List[Tuple[int, int]]:
+    """The parts of `ranges` inside [lo, hi)."""
+    return [(max(a, lo), min(b, hi)) for a, b in ranges if max(a, lo) < min(b, hi)]
+
+
+def cut_ranges(ranges: List[Tuple[int, int]], holes: List[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """`ranges` minus the (disjoint) `holes`."""
+    out = list(ranges)
+    for lo, hi in holes:
+        nxt = []
+        for a, b in out:
+            if a < min(b, lo):
+                nxt.append((a, min(b, lo)))
+            if max(a, hi) < b:
+                nxt.append((max(a, hi), b))
+        out = nxt
+    return sorted(out)
+
+
 class GradSync:
     """Averages the critic's (or any model's) flat gradient buffers across ranks.
 
     Bucket size: xGMI is point-to-point (7 links per GPU), so a ring all-reduce is bound by one
     link; 64 MiB fp32 buckets keep each collective bandwidth-bound (not latency-bound) while
-    letting RCCL pipeline consecutive buckets."""
+    letting RCCL pipeline consecutive buckets.
 
-    def __init__(self, stores, world: int, bucket_bytes: int = 64 << 20):
+    `overlap` (an encoder model whose store is among `stores`; RCCL only): the backward passes finish
+    the layers from the last to the first and record one event per layer; each layer's bucket is
+    queued behind its event on a side stream, so it travels while the rest of the pass still computes,
+    and only the embedding tables and the head wait for the end of the backward.  The host has
+    issued the whole backward when this object is called; the device is still early in it.
+
+    `position_rows`: bound on the positions any rank ever feeds (the padded width); the rest of the
+    position table holds zero gradients everywhere and is left out of the reduction."""
+
+    def __init__(self, stores, world: int, bucket_bytes: int = 64 << 20, overlap=None, position_rows=None):
         self.stores = list(stores)
         self.world = world
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = overlap
+        self._side = None
+        self._tail = None
+        if overlap is not None:
+            if not any(st is overlap.store for st in self.stores):
+                raise ValueError("overlap model's store is not among the stores to reduce")
+            if world > 1:
+                overlap.enable_layer_events()
+        if position_rows is not None:
+            for m in ([overlap] if overlap is not None else []):
+                m.limit_position_rows(position_rows)
+            if overlap is None:
+                raise ValueError("position_rows needs the model (overlap=...) whose position table it bounds")
+
+    def _plan(self):
+        """[(layer or None, store, lo, hi)] in issue order: layers last to first, then everything else."""
+        plan = []
+        rest = []
+        for store in self.stores:
+            if store.grad is None:
+                continue
+            live = live_ranges(store)
+            if self.overlap is not None and store is self.overlap.store:
+                spans = []
+                for l in reversed(range(self.overlap.config.num_hidden_layers)):
+                    lo, hi = self.overlap.layer_param_range(l)
+                    spans.append((lo, hi))
+                    for a, b in bucket_ranges(clip_ranges(live, lo, hi), self.bucket_elems):
+                        plan.append((l, store, a, b))
+                live = cut_ranges(live, sorted(spans))
+            for a, b in bucket_ranges(live, self.bucket_elems):
+                rest.append((None, store, a, b))
+        return plan + rest
 
     def __call__(self):
         if self.world <= 1:
             return
+        plan = self._plan()
+        rccl = dist.get_backend() == "nccl"
+        if rccl and self.overlap is not None and any(l is not None for l, *_ in plan):
+            return self._overlapped(plan)
         works = []
-        for store in self.stores:
-            if store.grad is None:
-                continue
-            for a, b in bucket_ranges(live_ranges(store), self.bucket_elems):
-                chunk = store.grad[a:b]
-                if chunk.is_cuda and dist.get_backend() == "nccl":
-                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
-                elif chunk.is_cuda:  # gloo (rehearsal only): stage through the host, it has no AVG either
-                    host = chunk.cpu()
-                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                    chunk.copy_(host.div_(self.world))
-                else:
-                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-                    chunk.div_(self.world)
+        for _, store, a, b in plan:
+            chunk = store.grad[a:b]
+            if chunk.is_cuda and rccl:
+                works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+            elif chunk.is_cuda:  # gloo (rehearsal only): stage through the host, it has no AVG either
+                host = chunk.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                chunk.copy_(host.div_(self.world))
+            else:
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+                chunk.div_(self.world)
         for w in works:
             w.wait()
+
+    def _overlapped(self, plan):
+        dev = self.overlap.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+            self._tail = torch.cuda.Event()
+        events = self.overlap.enable_layer_events()
+        self._tail.record(main)  # everything the backward has issued
+        works = []
+        with torch.cuda.stream(self._side):
+            waited = None
+            for l, store, a, b in plan:
+                if l != waited:
+                    self._side.wait_event(events[l] if l is not None else self._tail)
+                    waited = l
+                # the collective is ordered behind the side stream, i.e. behind that layer's event only
+                works.append(dist.all_reduce(store.grad[a:b], op=dist.ReduceOp.AVG, async_op=True))
+        for w in works:
+            w.wait()  # the optimizer step on the main stream comes after every bucket
 
 
 def generate_sharded(generate_fn, num_sequences: int, rank: int, world: int, rng_seed: int, **kw) -> List[str]:

@@ -317,11 +317,30 @@ def test_grad_sync_over_rccl_one_rank(pg, tmp_path):
         sync = GradSync([critic.protbert.store, critic.classifier.store], world=2, bucket_bytes=1 << 16)
         T.critic_update(critic, NoStep(), real, rm, fake, T.GanHyper(lambda_gp=5.0), grad_sync=sync, alpha=alpha)
         torch.cuda.synchronize()
+        plain = {n: p.grad.clone() for n, p in critic.named_parameters() if p.grad is not None}
+        # layer buckets queued behind the per-layer events of the backward passes, on a side stream
+        sync = GradSync([critic.protbert.store, critic.classifier.store], world=2, bucket_bytes=1 << 16,
+                        overlap=critic.protbert, position_rows=S)
+        T.critic_update(critic, NoStep(), real, rm, fake, T.GanHyper(lambda_gp=5.0), grad_sync=sync, alpha=alpha)
+        plan = sync._plan()
+        torch.cuda.synchronize()
+        layers = [l for l, *_ in plan]
+        assert layers[0] == c.num_hidden_layers - 1 and layers[-1] is None and 0 in layers
+        covered = sum(b - a for _, st, a, b in plan if st is critic.protbert.store)
+        H = c.hidden_size
+        live_all = sum(p.numel() for p in critic.protbert.parameters() if p.grad is not None)
+        skipped = (c.max_position_embeddings - S) * H  # position rows beyond the promised width
+        assert 0 <= covered - (live_all - skipped) <= 8 * len(critic.protbert.store.views)  # alignment gaps
+        got = {n: p.grad.clone() for n, p in critic.named_parameters() if p.grad is not None}
+        with pytest.raises(ValueError):  # a wider batch than the promised bound
+            wide = torch.randint(5, 25, (B, S + 8), device=DEV)
+            critic(wide, attention_mask=torch.ones(B, S + 8, device=DEV)).sum().backward()
     finally:
         dist.destroy_process_group()
-    got = {n: p.grad for n, p in critic.named_parameters() if p.grad is not None}
-    assert got.keys() == want.keys() and len(got) > 10
+    assert got.keys() == want.keys() == plain.keys() and len(got) > 10
     for n in want:
+        err = float((plain[n] - want[n]).abs().max())
+        assert err <= 1e-5 * float(want[n].abs().max()) + 1e-9, (n, err)
         # atomically accumulated bias gradients may differ in summation order between two runs
         err = float((got[n] - want[n]).abs().max())
         assert err <= 1e-5 * float(want[n].abs().max()) + 1e-9, (n, err)
