@@ -99,3 +99,51 @@ def test_shard_and_bucket_helpers():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     assert D.bucket_ranges([(0, 10), (20, 45)], 10) == [(0, 10), (20, 30), (30, 40), (40, 45)]
+
+
+def test_layerwise_plan_order_and_coverage():
+    """GradSync's issue order with an encoder to overlap with: the buckets of the last layer first,
+    layer 0 last among the layers, then what lies outside the layers (embedding tables, head); every
+    live element exactly once; the position table cut at the promised width."""
+    pgload.load()
+    from protgen_gan_amd import distributed as D
+    assert D.clip_ranges([(0, 10), (20, 45)], 5, 30) == [(5, 10), (20, 30)]
+    assert D.cut_ranges([(0, 100)], [(10, 20), (40, 50)]) == [(0, 10), (20, 40), (50, 100)]
+    assert D.cut_ranges([(0, 10), (30, 60)], [(5, 35)]) == [(0, 5), (35, 60)]
+
+    L, per_layer, pos_rows, H = 3, 96, 16, 8
+    pos = torch.nn.Parameter(torch.zeros(pos_rows, H))
+    head = torch.nn.Parameter(torch.zeros(24))
+    layers = [torch.nn.Parameter(torch.zeros(per_layer)) for _ in range(L)]
+    store = _FakeStore([pos] + layers + [head])
+    store.live_elems = {}
+
+    class Model:
+        config = type("Cfg", (), {"num_hidden_layers": L})()
+
+        def __init__(self):
+            self.store = store
+
+        def enable_layer_events(self):
+            raise AssertionError("events are for more than one rank")
+
+        def layer_param_range(self, l):
+            off = store.views[1 + l][1]
+            return off, off + per_layer
+
+        def limit_position_rows(self, rows):
+            store.live_elems[store.views[0][1]] = rows * H
+
+    sync = D.GradSync([store], world=1, bucket_bytes=4 * 40, overlap=Model(), position_rows=4)
+    plan = sync._plan()
+    order = [l for l, *_ in plan]
+    assert order == [2, 2, 2, 1, 1, 1, 0, 0, 0, None, None]
+    assert all(b - a <= 40 for _, _, a, b in plan)
+    seen = torch.zeros(store.grad.numel(), dtype=torch.int32)
+    for _, _, a, b in plan:
+        seen[a:b] += 1
+    want = torch.zeros_like(seen)
+    want[:4 * H] = 1  # the position rows inside the bound
+    for p, off, n in store.views[1:]:
+        want[off:off + n] = 1
+    assert torch.equal(seen, want)
