@@ -130,6 +130,10 @@ int pg_embed_ln(int dtype, const int64_t* ids, const float* word, const float* p
 int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
                  const float* gamma, const float* beta, float eps, void* out, void* sum_out, int B, int S, int H,
                  void* stream);
+/* Same for T tokens with explicit positions (device int32 pos_ids[T]): rows of several sequences back to back. */
+int pg_embed_ln_packed(int dtype, const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
+                       const float* type0, const float* gamma, const float* beta, float eps, void* out, int T, int H,
+                       void* stream);
 /* y = LayerNorm(x) (modeling_bert.py:289-293,347-351; residual is added by the GEMM epilogue). */
 int pg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                  int rows, int H, void* stream);
@@ -165,6 +169,10 @@ int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float*
  * + keymask) V straight from the packed [T][3H] QKV buffer, bf16 only, S <= 2048. */
 int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
                      int64_t ld_qkv, int64_t ld_ctx, void* stream);
+/* Same over sequences of different lengths laid back to back: sequence b = token rows
+ * [seq_off[b], seq_off[b+1]) of qkv / mask / ctx (device int32 seq_off[nseq+1], lengths <= max_len). */
+int pg_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* ctx, const int32_t* seq_off, int nseq,
+                            int max_len, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream);
 /* Same, additionally writing the probabilities P (activation dtype, [B*heads][S][pg_score_ld(S)],
  * zeros in the padding columns) that the backward and gradient-penalty passes consume. */
 int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
@@ -280,6 +288,15 @@ int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int S);
 int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
                        const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes, void* stash,
                        void* hidden_out, void* emb_sum_out, void* stream);
+/* The same forward for sequences of different lengths laid back to back ("packed"; bf16, inference only):
+ * sequence b is token rows [seq_off[b], seq_off[b+1]) of ids / pos_ids / mask / hidden_out (all T rows,
+ * T <= nseq*max_len; seq_off and pos_ids are device int32, pos_ids[t] = position of token t in its
+ * sequence).  Used by the stacked fill (several generate() batches of different padded widths in one
+ * pass, models.py:18-64 per batch): columns beyond a batch's own width cost nothing.  workspace as for
+ * pg_workspace_bytes(cfg, dtype, nseq, max_len).                                                      */
+int pg_encoder_forward_packed(const pg_model_cfg* cfg, const pg_params* p, int dtype, int nseq, int max_len,
+                              const int32_t* seq_off, int T, const int64_t* ids, const int32_t* pos_ids, const float* mask,
+                              void* workspace, int64_t workspace_bytes, void* hidden_out, void* stream);
 /* MLM head up to logits (Generator.forward, models.py:14-16): fp32 logits [T][V]. */
 int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T, void* workspace,
                   int64_t workspace_bytes, float* logits, void* stream);

@@ -549,6 +549,21 @@ class ProtBertForMaskedLM(nn.Module):
               "pg_encoder_forward")
         return hidden, stash
 
+    def _encode_packed(self, ids_p, pos_ids, seq_off, mask_p, nseq, max_len):
+        """Inference forward over `nseq` sequences of different lengths laid back to back in the T rows of
+        `ids_p` (int64), `pos_ids` (int32), `mask_p` (fp32 0/1); `seq_off` int32 [nseq+1].  -> hidden [T,H]."""
+        if self.compute_dtype != torch.bfloat16:
+            raise ValueError("the packed forward exists for bf16 inference only")
+        T = ids_p.numel()
+        dt = ops.dt_code(self.compute_dtype)
+        ws, n = self._ws(nseq, max_len)
+        hidden = torch.empty(T, self.config.hidden_size, dtype=self.compute_dtype, device=self.device)
+        pr = _params_struct(self.store, self.compute_dtype, False)
+        check(lib.pg_encoder_forward_packed(C.byref(self._ccfg), C.byref(pr), dt, nseq, max_len, seq_off.data_ptr(), T,
+                                            ids_p.data_ptr(), pos_ids.data_ptr(), ops.ptr(mask_p), ws.data_ptr(), n,
+                                            hidden.data_ptr(), ops.stream()), "pg_encoder_forward_packed")
+        return hidden
+
     def _encode_backward(self, stash, dh, B, S, param_grads, adj_stash=None):
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(B, S)
@@ -581,11 +596,12 @@ class ProtBertForMaskedLM(nn.Module):
               "pg_encoder_backward2")
         return xbar
 
-    def lm_logits(self, hidden):
-        """MLM head (dense -> GELU -> LayerNorm -> tied decoder + bias) -> fp32 [B,S,V]."""
+    def lm_logits(self, hidden, ws_shape=None):
+        """MLM head (dense -> GELU -> LayerNorm -> tied decoder + bias) -> fp32 [B,S,V].
+        `ws_shape`: the (B, S) whose workspace is large enough (packed rows: the unpacked shape)."""
         B, S, H = hidden.shape
         T = B * S
-        ws, n = self._ws(B, S)
+        ws, n = self._ws(*(ws_shape or (B, S)))
         logits = torch.empty(B, S, self.config.vocab_size, dtype=torch.float32, device=self.device)
         pr = _params_struct(self.store, self.compute_dtype, False)
         check(lib.pg_mlm_logits(C.byref(self._ccfg), C.byref(pr), ops.dt_code(self.compute_dtype), hidden.data_ptr(), T,

@@ -57,21 +57,29 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long
 }
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
-                                                           bf16_t* __restrict__ ctx, int S, int heads, long ld_qkv, long ld_ctx) {
+                                                           bf16_t* __restrict__ ctx, int S, int heads, long ld_qkv, long ld_ctx,
+                                                           const int* __restrict__ seq_off) {
   // [buffer][K|V] tiles, then the additive key mask (fp32) of this batch row.  One array only:
   // a second __shared__ object would make the compiler drain the LDS-DMA before LDS reads.
   __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;  // the query tiles of one head share an XCD's L2
   const int b = bh / heads, h = bh % heads;
+  // packed rows: sequence b occupies token rows [seq_off[b], seq_off[b+1]) and the grid is sized for the longest
+  long row0 = (long)b * S;
+  if (seq_off) {
+    row0 = seq_off[b];
+    S = seq_off[b + 1] - seq_off[b];
+    if (qt * QB >= S) return;
+  }
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int H = heads * 64;
-  const bf16_t* Q = qkv + (long)b * S * ld_qkv + h * 64;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
   const bf16_t* K = Q + H;
   const bf16_t* V = Q + 2 * H;
-  const float* mrow = mask ? mask + (long)b * S : nullptr;
+  const float* mrow = mask ? mask + row0 : nullptr;
   const int q0 = qt * QB + wid * 32;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32kk + 8g .. +8]
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int q = q0 + qg * 16 + r;
     if (q >= S) continue;
     const float inv = 1.0f / l_run[qg];
-    bf16_t* dst = ctx + ((long)b * S + q) * ld_ctx + h * 64 + 4 * g;
+    bf16_t* dst = ctx + (row0 + q) * ld_ctx + h * 64 + 4 * g;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       float v[4] = {o[qg][d][0] * inv, o[qg][d][1] * inv, o[qg][d][2] * inv, o[qg][d][3] * inv};
@@ -1056,7 +1064,18 @@ extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, v
   if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return PG_ERR_ALIGN;
   dim3 grid((S + QB - 1) / QB, B * heads);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, S,
-                     heads, (long)ld_qkv, (long)ld_ctx);
+                     heads, (long)ld_qkv, (long)ld_ctx, (const int*)nullptr);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* ctx, const int32_t* seq_off,
+                                       int nseq, int max_len, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!qkv || !ctx || !seq_off || nseq <= 0 || max_len <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || max_len > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return PG_ERR_ALIGN;
+  dim3 grid((max_len + QB - 1) / QB, nseq * heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, max_len,
+                     heads, (long)ld_qkv, (long)ld_ctx, seq_off);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 

@@ -251,24 +251,35 @@ extern "C" int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int
 }
 
 // ------------------------------------------------------------------ forward
-extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
-                                  const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes,
-                                  void* stash, void* hidden_out, void* emb_sum_out, void* stream) {
+// Packed form (seq_off != NULL; inference, bf16, ids only): the B sequences have their own lengths
+// seq_off[b+1] - seq_off[b] <= S and lie back to back in T_packed token rows; every token-wise kernel
+// runs on T_packed rows, attention walks each sequence's own keys.  Buffers are laid out for B x S.
+static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
+                        const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes, void* stash,
+                        void* hidden_out, void* emb_sum_out, void* stream, const int32_t* seq_off, const int32_t* pos_ids,
+                        int T_packed) {
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !p->master || (!ids && !x_in) || !workspace) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   if (!stash && !hidden_out) return PG_ERR_ARG;
   if (d.ldS > 1024 && !(!stash && dtype == PG_BF16 && S <= 2048)) return PG_ERR_UNSUPPORTED;
+  if (seq_off && (!ids || !pos_ids || stash || emb_sum_out || T_packed <= 0 || T_packed > d.T)) return PG_ERR_ARG;
+  if (seq_off && !(dtype == PG_BF16 && S <= 2048)) return PG_ERR_UNSUPPORTED;
   Workspace w = ws_layout(d, (char*)workspace);
   if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ParamView pv{cfg, p, dtype};
   G g{dtype, st};
-  const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
+  const int es = d.es, H = d.H, I = d.I, T = seq_off ? T_packed : (int)d.T;
   StashLayout sl = stash_layout(d);
 
   char* x = stash ? (char*)stash + sl.xs : w.x0;
-  if (ids) {
+  if (seq_off) {
+    CK(pg_embed_ln_packed(dtype, ids, pos_ids, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)),
+                          pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)),
+                          pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)),
+                          cfg->ln_eps, x, T, H, st));
+  } else if (ids) {
     CK(pg_embed_ln2(dtype, ids, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)),
                     pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)),
                     pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)), cfg->ln_eps, x, emb_sum_out, B, S, H, st));
@@ -287,7 +298,9 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
     // QKV projection (BertSelfAttention.query/key/value as one [3H,H] matrix)
     CK(g.run(s.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, s.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f,
              pv.m(pv.lo(l, PG_L_BQ))));
-    if (!stash && dtype == PG_BF16 && S <= 2048) {
+    if (seq_off) {
+      CK(pg_attention_fwd_packed(dtype, s.qkv, mask, s.ctx, seq_off, B, S, d.nh, 3 * H, H, st));
+    } else if (!stash && dtype == PG_BF16 && S <= 2048) {
       // nothing is kept for a backward: fused attention, no score matrix in HBM
       CK(pg_attention_fwd(dtype, s.qkv, mask, s.ctx, B, S, d.nh, 3 * H, H, st));
     } else if (stash && dtype == PG_BF16 && S <= 2048) {
@@ -318,6 +331,22 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
     if (hipMemcpyAsync(hidden_out, x, (size_t)d.T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
   return PG_OK;
+}
+
+extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
+                                  const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes,
+                                  void* stash, void* hidden_out, void* emb_sum_out, void* stream) {
+  return forward_impl(cfg, p, dtype, B, S, ids, x_in, mask, workspace, workspace_bytes, stash, hidden_out, emb_sum_out, stream,
+                      nullptr, nullptr, 0);
+}
+
+extern "C" int pg_encoder_forward_packed(const pg_model_cfg* cfg, const pg_params* p, int dtype, int nseq, int max_len,
+                                         const int32_t* seq_off, int T, const int64_t* ids, const int32_t* pos_ids,
+                                         const float* mask, void* workspace, int64_t workspace_bytes, void* hidden_out,
+                                         void* stream) {
+  if (!seq_off || !hidden_out) return PG_ERR_ARG;
+  return forward_impl(cfg, p, dtype, nseq, max_len, ids, nullptr, mask, workspace, workspace_bytes, nullptr, hidden_out, nullptr,
+                      stream, seq_off, pos_ids, T);
 }
 
 // MLM head: t = LN(gelu(hidden W^T + b)) ; logits = t word^T + bias

@@ -58,12 +58,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                                                         const float* __restrict__ pos, const float* __restrict__ type0,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, T* __restrict__ out, T* __restrict__ sum_out, int B,
-                                                        int S, int H) {
+                                                        int S, int H, const int* __restrict__ pos_ids) {
   constexpr int N = VW * NCH;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= (long)B * S) return;
-  const int s = (int)(row % S);
+  const int s = pos_ids ? pos_ids[row] : (int)(row % S);
   const long id = ids[row];
   float w[N], p[N], t[N], g[N], b[N], x[N];
   row_load<float, VW, NCH>(word + id * H, lane, w);
@@ -495,20 +495,31 @@ inline int row_blocks(long rows) { return (int)((rows + ROWS_PER_BLOCK - 1) / RO
 extern "C" int pg_ln_partial_rows(int rows) { return rows < 1024 ? rows : 1024; }
 extern "C" int pg_score_ld(int S) { return ((S + 63) / 64) * 64; }
 
-extern "C" int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
-                            const float* gamma, const float* beta, float eps, void* out, void* sum_out, int B, int S, int H,
-                            void* stream) {
+static int embed_ln_launch(int dtype, const int64_t* ids, const int* pos_ids, const float* word, const float* pos,
+                           const float* type0, const float* gamma, const float* beta, float eps, void* out, void* sum_out,
+                           int B, int S, int H, void* stream) {
   if (!ids || !word || !pos || !type0 || !gamma || !beta || !out || B <= 0 || S <= 0) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = row_blocks((long)B * S);
   if (dtype == PG_F32) {
     ROW_DISPATCH(H, hipLaunchKernelGGL((embed_ln_kernel<float, VW, NCH>), dim3(blocks), dim3(256), 0, st, ids, word, pos,
-                                        type0, gamma, beta, eps, (float*)out, (float*)sum_out, B, S, H));
+                                        type0, gamma, beta, eps, (float*)out, (float*)sum_out, B, S, H, pos_ids));
   } else {
     ROW_DISPATCH(H, hipLaunchKernelGGL((embed_ln_kernel<bf16_t, VW, NCH>), dim3(blocks), dim3(256), 0, st, ids, word, pos,
-                                        type0, gamma, beta, eps, (bf16_t*)out, (bf16_t*)sum_out, B, S, H));
+                                        type0, gamma, beta, eps, (bf16_t*)out, (bf16_t*)sum_out, B, S, H, pos_ids));
   }
   return check_launch();
+}
+extern "C" int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
+                            const float* gamma, const float* beta, float eps, void* out, void* sum_out, int B, int S, int H,
+                            void* stream) {
+  return embed_ln_launch(dtype, ids, nullptr, word, pos, type0, gamma, beta, eps, out, sum_out, B, S, H, stream);
+}
+extern "C" int pg_embed_ln_packed(int dtype, const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
+                                  const float* type0, const float* gamma, const float* beta, float eps, void* out, int T,
+                                  int H, void* stream) {
+  if (!pos_ids) return PG_ERR_ARG;
+  return embed_ln_launch(dtype, ids, pos_ids, word, pos, type0, gamma, beta, eps, out, nullptr, 1, T, H, stream);
 }
 extern "C" int pg_embed_ln(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
                            const float* gamma, const float* beta, float eps, void* out, int B, int S, int H, void* stream) {

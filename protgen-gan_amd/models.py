@@ -14,6 +14,26 @@ from ._lib import check, lib
 from .bert import FlatStore, ProtBertForMaskedLM
 
 
+class RowPacking:
+    """Which columns of a [B,S] id matrix belong to each row's own batch (`widths[b]` leading columns),
+    as index tensors for the packed encoder pass: built once, reused by every fill iteration."""
+
+    def __init__(self, widths, S: int, device):
+        widths = [int(w) for w in widths]
+        if not widths or min(widths) < 1 or max(widths) > S:
+            raise ValueError("row widths must lie in 1..S")
+        off = [0]
+        for w in widths:
+            off.append(off[-1] + w)
+        self.widths, self.S, self.T = widths, S, off[-1]
+        self.offsets = off
+        rows = torch.repeat_interleave(torch.arange(len(widths)), torch.tensor(widths))
+        pos = torch.arange(self.T) - torch.tensor(off[:-1])[rows]
+        self.idx = (rows * S + pos).to(device)                       # flat index into [B*S]
+        self.pos = pos.to(torch.int32).to(device)
+        self.seq_off = torch.tensor(off, dtype=torch.int32).to(device)
+
+
 class Generator(nn.Module):
     def __init__(self, protbert_model, cls_token_id=2, sep_token_id=3, mask_token_id=4, pad_token_id=0):
         super().__init__()
@@ -43,16 +63,22 @@ class Generator(nn.Module):
                                current_rate, noise)
 
     @torch.no_grad()
-    def generate_groups(self, input_ids, attention_mask, groups, keep_percent=0.1, current_rate=None, noise=None):
+    def generate_groups(self, input_ids, attention_mask, groups, keep_percent=0.1, current_rate=None, noise=None,
+                        packing: "RowPacking | None" = None):
         """The same fill step for several independent batches stacked along dim 0, one encoder
         pass for all of them.  `groups` = [(row_begin, row_end, temperature), ...] covers the
         rows; each group is sampled at its own temperature, exactly as separate generate()
         calls on the row slices would (rows never interact: attention is per sequence and the
-        top-k commit is per row)."""
-        return self._fill_step(input_ids, attention_mask, [(int(a), int(b), float(t)) for a, b, t in groups],
-                               keep_percent, current_rate, noise)
+        top-k commit is per row).
 
-    def _fill_step(self, input_ids, attention_mask, groups, keep_percent, current_rate, noise):
+        `packing` (bf16 only): the batches have different padded widths and the columns beyond a
+        row's own batch hold nothing (pad ids, never attended).  The encoder pass then runs on
+        the kept columns only, laid back to back; tokens, confidences and commits are those of
+        the full-width pass."""
+        return self._fill_step(input_ids, attention_mask, [(int(a), int(b), float(t)) for a, b, t in groups],
+                               keep_percent, current_rate, noise, packing)
+
+    def _fill_step(self, input_ids, attention_mask, groups, keep_percent, current_rate, noise, packing=None):
         m: ProtBertForMaskedLM = self.protbert
         ids = m._check_ids(input_ids)
         inplace = ids.data_ptr() == input_ids.data_ptr()
@@ -62,6 +88,8 @@ class Generator(nn.Module):
         if covered[0][0] != 0 or covered[-1][1] != B or any(x[1] != y[0] for x, y in zip(covered, covered[1:])):
             raise ValueError("groups must partition the rows of input_ids")
         mask = m._mask01(attention_mask, B, S)
+        if packing is not None and packing.T < B * S:
+            return self._fill_step_packed(input_ids, ids, mask, groups, keep_percent, current_rate, noise, packing)
         hidden, _ = m._encode(ids, None, mask, want_stash=False)
         logits = m.lm_logits(hidden).view(B * S, V)
         if noise is None:
@@ -84,6 +112,42 @@ class Generator(nn.Module):
         if len(self.fill_shapes) < 100000:
             self.fill_shapes.append((B, S))
         if not inplace:
+            input_ids.copy_(ids)
+        return input_ids
+
+
+    def _fill_step_packed(self, input_ids, ids, mask, groups, keep_percent, current_rate, noise, pk):
+        m: ProtBertForMaskedLM = self.protbert
+        B, S = ids.shape
+        V = m.config.vocab_size
+        if pk.S != S or len(pk.widths) != B:
+            raise ValueError("packing was built for another shape")
+        if mask is None:
+            mask = torch.ones(B, S, dtype=torch.float32, device=ids.device)
+        T = pk.T
+        hidden = m._encode_packed(ids.view(-1)[pk.idx], pk.pos, pk.seq_off, mask.view(-1)[pk.idx], B, S)
+        logits = m.lm_logits(hidden.view(1, T, -1), ws_shape=(B, S)).view(T, V)
+        if noise is None:
+            noise = torch.empty(T, V, dtype=torch.float32, device=ids.device).exponential_(1.0)
+        else:
+            noise = noise.to(device=ids.device, dtype=torch.float32).contiguous().view(B * S, V)[pk.idx]
+        pred_p = torch.empty(T, dtype=torch.long, device=ids.device)
+        conf_p = torch.empty(T, dtype=torch.float32, device=ids.device)
+        for a, b, t in groups:
+            lo, hi = pk.offsets[a], pk.offsets[b]
+            ops.sample_tokens(logits[lo:hi], noise[lo:hi], t, pred=pred_p[lo:hi], conf=conf_p[lo:hi])
+        # columns outside a row's batch hold pad ids: the commit never looks at their prediction
+        pred = torch.zeros(B * S, dtype=torch.long, device=ids.device).index_copy_(0, pk.idx, pred_p)
+        conf = torch.zeros(B * S, dtype=torch.float32, device=ids.device).index_copy_(0, pk.idx, conf_p)
+        fill_all = current_rate is not None and current_rate <= 0.1
+        counts = torch.empty(B, 2, dtype=torch.int32, device=ids.device)
+        ops.commit_topk(ids, pred, conf, float(keep_percent), fill_all, self.mask_token_id, self.pad_token_id,
+                        self.cls_token_id, self.sep_token_id, counts)
+        self.last_counts = counts
+        self.fill_calls += 1
+        if len(self.fill_shapes) < 100000:
+            self.fill_shapes.append((B, S))
+        if ids.data_ptr() != input_ids.data_ptr():
             input_ids.copy_(ids)
         return input_ids
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from .loss import compute_gradient_penalty, critic_loss, generator_loss
-from .models import Critic, Generator
+from .models import Critic, Generator, RowPacking
 
 
 @dataclass
@@ -110,7 +110,7 @@ def fill_temperatures(hp: GanHyper) -> List[float]:
 
 def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequence[int]],
                           temps_per_batch: Sequence[Sequence[float]], hp: GanHyper, device, mask_id=4, cls_id=2,
-                          sep_id=3, pad_id=0) -> List[torch.Tensor]:
+                          sep_id=3, pad_id=0, packed: bool = True) -> List[torch.Tensor]:
     """Several blind-mode fake batches filled together: the generator's weights do not change
     between them, so their fill passes run as one stacked batch (one encoder pass per fill
     iteration for all of them) instead of one batch after the other.  Each batch keeps what a
@@ -132,11 +132,17 @@ def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequ
             inside[r, :w] = True
             r += 1
     ids, inside = ids.to(device), inside.to(device)
+    # bf16: the encoder passes skip the columns beyond each batch's own width (they are outside its attention
+    # and its output); fp32 keeps the rectangular pass
+    packing = None
+    if packed and generator.protbert.compute_dtype == torch.bfloat16 and len(set(widths)) > 1:
+        packing = RowPacking([w for ls, w in zip(lengths_per_batch, widths) for _ in ls], S, device)
     rate, it = hp.initial_masking_rate, 0
     while rate > 0:
         attn = ((ids != mask_id) & inside).long()
         groups = [(a, b, temps[it]) for (a, b), temps in zip(spans, temps_per_batch)]
-        ids = generator.generate_groups(ids, attn, groups, keep_percent=hp.iteration_fill_rate, current_rate=rate)
+        ids = generator.generate_groups(ids, attn, groups, keep_percent=hp.iteration_fill_rate, current_rate=rate,
+                                        packing=packing)
         if generator.fill_shapes and generator.fill_shapes[-1] == (rows, S):
             # throughput bookkeeping counts each batch at its own width, not the stacked one
             generator.fill_shapes[-1:] = [(b - a, w) for (a, b), w in zip(spans, widths)]

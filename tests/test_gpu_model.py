@@ -386,6 +386,50 @@ def test_generate_groups_matches_separate_calls(pg):
     assert int(gen.last_counts[:, 0].sum()) > 0  # the fill-all pass committed something
 
 
+@pytest.mark.parametrize("name,widths", [("tiny", (30, 40, 17)), ("mid", (136, 200, 129))])
+def test_packed_fill_matches_rectangular(pg, name, widths):
+    """Stacked bf16 fill with the columns beyond each batch's width left out of the encoder pass
+    (rows laid back to back, attention over each row's own keys) against the rectangular pass on the
+    same Exp(1) draws: the same hidden rows at the kept columns, the same tokens and counts."""
+    from protgen_gan_amd.models import RowPacking
+    c, P, PC, C, gen, critic = build(pg, name, torch.bfloat16)
+    V, S = c.vocab_size, max(widths)
+    g = torch.Generator().manual_seed(11)
+    rows_per = (2, 3, 2)
+    lens = [[int(torch.randint(w // 2, w + 1, (1,), generator=g)) for _ in range(n - 1)] + [w] for n, w in zip(rows_per, widths)]
+    B = sum(rows_per)
+    st = torch.full((B, S), O.PAD, dtype=torch.long)
+    inside = torch.zeros(B, S, dtype=torch.bool)
+    groups, row_w, r = [], [], 0
+    for ls, w, t in zip(lens, widths, (0.9, 1.1, 1.0)):
+        st[r:r + len(ls), :w] = _blind_template(ls, w)
+        inside[r:r + len(ls), :w] = True
+        groups.append((r, r + len(ls), t))
+        row_w += [w] * len(ls)
+        r += len(ls)
+    st, inside = st.to(DEV), inside.to(DEV)
+    pk = RowPacking(row_w, S, DEV)
+    assert pk.T == sum(row_w) < B * S
+
+    m = gen.protbert
+    attn = ((st != O.MASK) & inside).float()
+    dense, _ = m._encode(st, None, attn, want_stash=False)
+    packed = m._encode_packed(st.view(-1)[pk.idx], pk.pos, pk.seq_off, attn.view(-1)[pk.idx], B, S)
+    d = dense.view(B * S, -1)[pk.idx].float()
+    assert float((packed.float() - d).abs().max()) <= 2e-2 * float(d.abs().max())
+
+    a, b = st.clone(), st.clone()
+    for rate in (0.9, 0.5, 0.1):
+        ns = torch.empty(B * S, V).exponential_(1.0, generator=g)
+        a = gen.generate_groups(a, ((a != O.MASK) & inside).long(), groups, keep_percent=0.3, current_rate=rate, noise=ns)
+        ca = gen.last_counts.clone()
+        b = gen.generate_groups(b, ((b != O.MASK) & inside).long(), groups, keep_percent=0.3, current_rate=rate, noise=ns,
+                                packing=pk)
+        assert torch.equal(gen.last_counts, ca)
+        assert torch.equal(a, b), f"rate {rate}: {int((a != b).sum())} tokens differ"
+    assert bool((b[~inside] == O.PAD).all())
+
+
 def test_stacked_blind_generation_shapes(pg):
     from protgen_gan_amd import train as T
     c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
