@@ -1190,6 +1190,7 @@ int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring dep
 
 int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
 
+extern int pg_internal_colsum_chunks;
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
@@ -1200,6 +1201,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
   if (key == 11) { g_gemm_group = value; return PG_OK; }
+  if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }

@@ -619,6 +619,7 @@ extern "C" int pg_gelu_bwd2(int dtype, const void* u, const void* udot, const vo
   return check_launch();
 }
 
+int pg_internal_colsum_chunks = 32;  // most row chunks of one column-sum launch (pg_tune key 12)
 extern "C" int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, int N, float* db, void* stream) {
   if (!dY || !db || rows <= 0 || N <= 0) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -627,8 +628,9 @@ extern "C" int pg_colsum_acc(int dtype, const void* dY, int64_t ld, int rows, in
     // at most 32 row chunks: every chunk ends in one atomic per column, and many workgroups adding
     // into the same few KiB at once serialise
     const int gx = (N + 64 * E - 1) / (64 * E);
-    int chunks = rows / 64;
-    chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
+    int chunks = rows / 64;  // at most 32 chunks below 8192 rows, 64 from there on (measured best for both)
+    const int cap = rows >= 8192 ? 2 * pg_internal_colsum_chunks : pg_internal_colsum_chunks;
+    chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
     const int rpc = ((rows + chunks - 1) / chunks + 3) / 4 * 4;
     dim3 grid(gx, (rows + rpc - 1) / rpc);
     if (dtype == PG_F32)
