@@ -65,6 +65,9 @@ struct Workspace {
   char* qkv; char* ctx; char* a; char* h; char* u; char* gu; char* f; char* x0; char* x1;
   float* ln_partial;
   float* mlm_tmp;  // unused by the encoder passes
+  // the operands a layer's weight gradients read (f, u, qkv, a), four sets: the gradients of up to four
+  // layers are launched together, so a set must outlive the three layers that follow (set 0 = f, u, qkv, a)
+  char* rf[4]; char* ru[4]; char* rqkv[4]; char* ra[4];
   long total_bytes;
 };
 
@@ -88,6 +91,13 @@ Workspace ws_layout(const Dims& d, char* base) {
   w.x1 = take(d.T * d.H * d.es);
   w.ln_partial = (float*)take(3L * d.H * 1024 * 4);
   w.mlm_tmp = nullptr;
+  w.rf[0] = w.f; w.ru[0] = w.u; w.rqkv[0] = w.qkv; w.ra[0] = w.a;
+  for (int i = 1; i < 4; ++i) {
+    w.rf[i] = take(d.T * d.H * d.es);
+    w.ru[i] = take(d.T * d.I * d.es);
+    w.rqkv[i] = take(d.T * 3 * d.H * d.es);
+    w.ra[i] = take(d.T * d.H * d.es);
+  }
   w.total_bytes = o;
   return w;
 }
@@ -160,6 +170,52 @@ struct G {
     return pg_gemm(&d, st);
   }
 };
+
+// Weight gradients of consecutive layers, launched together.  One layer's four products make
+// 64 + 64 + 48 + 16 = 192 tiles of 256x256 at ProtBERT's sizes: three quarters of the 256 CUs for the length
+// of one tile.  Four layers make 768 = three full rounds.  `depth` layers are collected (their operands stay
+// in separate buffer sets meanwhile), then one grouped launch; the layers' "gradients issued" events follow it.
+struct DwQueue {
+  pg_gemm_desc d[16];
+  int layers[4];
+  int n = 0, nl = 0, depth = 1;
+  hipStream_t st = nullptr;
+  void* const* done = nullptr;
+  int flush() {
+    if (!n) return PG_OK;
+    const int rc = pg_gemm_group(d, n, st);
+    if (rc != PG_OK) return rc;
+    if (done)
+      for (int i = 0; i < nl; ++i)
+        if (hipEventRecord((hipEvent_t)done[layers[i]], st) != hipSuccess) return PG_ERR_LAUNCH;
+    n = nl = 0;
+    return PG_OK;
+  }
+  int push(int layer, const pg_gemm_desc* four) {
+    for (int i = 0; i < 4; ++i) d[n++] = four[i];
+    layers[nl++] = layer;
+    return nl >= depth ? flush() : PG_OK;
+  }
+};
+}  // namespace
+int pg_internal_dw_depth = 0;  // 0 = choose by tile count; 1..4 = force (pg_tune key 13)
+namespace {
+// Layers per grouped launch: the count in 1..4 whose tiles fill whole rounds of the 256 CUs best.
+inline int dw_depth(const Dims& d, int dtype) {
+  if (pg_internal_dw_depth >= 1 && pg_internal_dw_depth <= 4) return pg_internal_dw_depth;
+  if (dtype != PG_BF16 || d.T % 64) return 1;
+  auto t = [](long m, long n) { return ((m + 255) / 256) * ((n + 255) / 256); };
+  const long per = 2 * t(d.H, d.I) + t(3L * d.H, d.H) + t(d.H, d.H);
+  if (per * 2 < 256) return 1;  // such products are not launched as one group of 256x256 tiles anyway
+  int best = 1;
+  double best_eff = 0.0;
+  for (int n = 1; n <= 4; ++n) {
+    const long tiles = per * n, rounds = (tiles + 255) / 256;
+    const double eff = (double)tiles / (double)(rounds * 256);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = n; }
+  }
+  return best;
+}
 
 // The tangent and second-order passes must agree on this: with the fused kernels the score slot
 // of the tangent stash holds rho ([B*heads][S] fp32), otherwise the tangent scores.
@@ -396,13 +452,16 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     Slots last = layer_slots((char*)adj_stash, sl, d, d.L - 1);
     if (hipMemcpyAsync(last.y, dy, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
+  DwQueue dwq;
+  dwq.st = st; dwq.done = layer_done; dwq.depth = grads ? dw_depth(d, dtype) : 1;
   for (int l = d.L - 1; l >= 0; --l) {
     const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
     Slots a;  // adjoint buffers of this layer
     if (save) {
       a = layer_slots((char*)adj_stash, sl, d, l);
     } else {
-      a.qkv = w.qkv; a.ss = w.ss0; a.ctx = w.ctx; a.a = w.a; a.h = w.h; a.u = w.u; a.gu = w.gu; a.f = w.f;
+      const int r = (d.L - 1 - l) % dwq.depth;
+      a.qkv = w.rqkv[r]; a.ss = w.ss0; a.ctx = w.ctx; a.a = w.ra[r]; a.h = w.h; a.u = w.ru[r]; a.gu = w.gu; a.f = w.rf[r];
       a.x = (dy == w.x0) ? w.x1 : w.x0;
     }
     if (l == 0 && dx_out && !save) a.x = (char*)dx_out;
@@ -449,14 +508,14 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
                                    g.dw_desc(a.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T),
                                    g.dw_desc(a.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T),
                                    g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T)};
-      CK(pg_gemm_group(dws, 4, st));
       CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
-      if (layer_done && hipEventRecord((hipEvent_t)layer_done[l], st) != hipSuccess) return PG_ERR_LAUNCH;
+      CK(dwq.push(l, dws));
     }
     // dx = dqkv Wqkv + da
     CK(g.run(a.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, a.x, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, a.a, H));
     dy = a.x;
   }
+  CK(dwq.flush());
   if (dx_out && dy != (char*)dx_out) {
     if (hipMemcpyAsync(dx_out, dy, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
@@ -535,28 +594,32 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
   const size_t th_bytes = (size_t)d.T * H * es;
 
   char* ybar = nullptr;  // second-order adjoint of the layer output (zero above the last layer)
+  DwQueue dwq;
+  dwq.st = st; dwq.done = layer_done; dwq.depth = grads ? dw_depth(d, dtype) : 1;
   for (int l = d.L - 1; l >= 0; --l) {
     const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
     const Slots a = layer_slots((char*)const_cast<void*>(adj_stash), sl, d, l);
     const Slots t = layer_slots((char*)const_cast<void*>(tan_stash), sl, d, l);
     char* xbar = (ybar == w.x0) ? w.x1 : w.x0;
+    const int r = (d.L - 1 - l) % dwq.depth;
+    char* const wf = w.rf[r]; char* const wu = w.ru[r]; char* const wqkv = w.rqkv[r]; char* const wa = w.ra[r];
     // LN2: fbar
-    CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, w.f,
+    CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, wf,
                          grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
                          grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
     // (W2bar = fbar^T gu + gf^T gudot and the other three weight gradients: one grouped launch at the end of the layer)
     // gubar = fbar W2 ; ubar = gelu'(u) gubar + gelu''(u) udot ggu
-    CK(g.run(w.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
-    CK(pg_gelu_bwd2(dtype, s.u, t.u, a.gu, w.gu, w.u, (int64_t)d.T * I, st));
-    if (grads) CK(pg_colsum_acc(dtype, w.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
+    CK(g.run(wf, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, w.gu, dtype, I, T, I, H, 1.f, 0.f));
+    CK(pg_gelu_bwd2(dtype, s.u, t.u, a.gu, w.gu, wu, (int64_t)d.T * I, st));
+    if (grads) CK(pg_colsum_acc(dtype, wu, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
     // hbar = ubar W1 + fbar
-    CK(g.run(w.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, w.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, w.f, H));
+    CK(g.run(wu, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, w.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, wf, H));
     // LN1: abar
-    CK(pg_layernorm_bwd2(dtype, s.a, t.a, a.h, w.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, w.a,
+    CK(pg_layernorm_bwd2(dtype, s.a, t.a, a.h, w.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, wa,
                          grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
                          grads ? pv.g(pv.lo(l, PG_L_BO)) : nullptr, w.ln_partial, T, H, st));  // (the Wo products pair with the QKV ones below)
     // ctxbar = abar Wo
-    CK(g.run(w.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
+    CK(g.run(wa, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention second order
     const char* v = off(s.qkv, 2 * H, es);
     const char* vdot = off(t.qkv, 2 * H, es);
@@ -570,33 +633,33 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
       CK(pg_softmax_bwd2(dtype, s.ss, t.ss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)d.Z, S, st));
     }
     // qbar = (Sbar K + gS Kdot)/8
-    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, w.qkv, dtype, 3 * H, false, S, 64, S,
+    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, wqkv, dtype, 3 * H, false, S, 64, S,
              0.125f, 0.f));
-    CK(g.bat(d, a.ss, true, d.ldS, true, off(t.qkv, H, es), false, 3 * H, false, w.qkv, dtype, 3 * H, false, S, 64, S,
+    CK(g.bat(d, a.ss, true, d.ldS, true, off(t.qkv, H, es), false, 3 * H, false, wqkv, dtype, 3 * H, false, S, 64, S,
              0.125f, 1.f));
     // kbar = (Sbar^T Q + gS^T Qdot)/8
-    CK(g.bat(d, w.ss0, false, d.ldS, true, s.qkv, false, 3 * H, false, off(w.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+    CK(g.bat(d, w.ss0, false, d.ldS, true, s.qkv, false, 3 * H, false, off(wqkv, H, es), dtype, 3 * H, false, S, 64, S,
              0.125f, 0.f));
-    CK(g.bat(d, a.ss, false, d.ldS, true, t.qkv, false, 3 * H, false, off(w.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+    CK(g.bat(d, a.ss, false, d.ldS, true, t.qkv, false, 3 * H, false, off(wqkv, H, es), dtype, 3 * H, false, S, 64, S,
              0.125f, 1.f));
     // vbar = P^T ctxbar + Pdot^T gctx
-    CK(g.bat(d, s.ss, false, d.ldS, true, w.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+    CK(g.bat(d, s.ss, false, d.ldS, true, w.ctx, false, H, false, off(wqkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              0.f));
-    CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(w.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+    CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(wqkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
              1.f));
     if (grads) {
-      const pg_gemm_desc dws[4] = {g.dw_desc(w.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu),
-                                   g.dw_desc(w.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h),
-                                   g.dw_desc(w.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T, a.qkv, t.x),
-                                   g.dw_desc(w.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx)};
-      CK(pg_gemm_group(dws, 4, st));
-      CK(pg_colsum_acc(dtype, w.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
-      if (layer_done && hipEventRecord((hipEvent_t)layer_done[l], st) != hipSuccess) return PG_ERR_LAUNCH;
+      const pg_gemm_desc dws[4] = {g.dw_desc(wf, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu),
+                                   g.dw_desc(wu, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h),
+                                   g.dw_desc(wqkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T, a.qkv, t.x),
+                                   g.dw_desc(wa, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T, a.a, t.ctx)};
+      CK(pg_colsum_acc(dtype, wqkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+      CK(dwq.push(l, dws));
     }
     // xbar = qkvbar Wqkv + abar
-    CK(g.run(w.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, xbar, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, w.a, H));
+    CK(g.run(wqkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, xbar, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, wa, H));
     ybar = xbar;
   }
+  CK(dwq.flush());
   if (xbar_out) {
     if (hipMemcpyAsync(xbar_out, ybar, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }

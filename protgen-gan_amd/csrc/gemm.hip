@@ -981,20 +981,22 @@ __global__ __launch_bounds__(NT256, 1) void gemm_glds256_kernel(GemmArgs g) {
   glds256_block<TC, AK, BK_, DBG>(g, A, B, Cp, txy, gridDim.x, gridDim.y, smem);
 }
 
-// Up to four unbatched products of one layout in one launch of 256x256 tiles: workgroups
+// Up to sixteen unbatched products of one layout in one launch of 256x256 tiles: workgroups
 // [first[i], first[i+1]) tile product i.  The four weight gradients of a transformer layer have
-// 64 + 64 + 48 + 16 such tiles: none covers the chip alone, together they nearly do, at twice the
-// operand reuse of 128x128 tiles.
-struct GemmArgsG { GemmArgs p[4]; int first[5]; int gx[4]; int gy[4]; };
+// 64 + 64 + 48 + 16 such tiles: none covers the chip alone, together they cover three quarters, those of
+// four layers three full rounds, at twice the operand reuse of 128x128 tiles.
+constexpr int GROUP_MAX = 16;
+struct GemmArgsG { GemmArgs p[GROUP_MAX]; int first[GROUP_MAX + 1]; int gx[GROUP_MAX]; int gy[GROUP_MAX]; };
+static_assert(sizeof(GemmArgsG) <= 4096, "kernel arguments are limited to 4 KiB");
 
 template <typename TC, bool AK, bool BK_>
 __global__ __launch_bounds__(NT256, 1) void gemm_glds256_group_kernel(GemmArgsG a) {
   __shared__ __align__(16) bf16_t smem[2 * 4 * GT_ELEMS];
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int i = 0;
-  if (lid >= a.first[1]) i = 1;
-  if (lid >= a.first[2]) i = 2;
-  if (lid >= a.first[3]) i = 3;
+#pragma unroll
+  for (int j = 1; j < GROUP_MAX; ++j)
+    if (lid >= a.first[j]) i = j;
   const GemmArgs& g = a.p[i];
   glds256_block<TC, AK, BK_, 0>(g, reinterpret_cast<const bf16_t*>(g.A), reinterpret_cast<const bf16_t*>(g.B),
                                 reinterpret_cast<TC*>(g.C), lid - a.first[i], a.gx[i], a.gy[i], smem);
@@ -1191,6 +1193,7 @@ int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring dep
 int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
 
 extern int pg_internal_colsum_chunks;
+extern int pg_internal_dw_depth;
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
@@ -1201,6 +1204,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
   if (key == 11) { g_gemm_group = value; return PG_OK; }
+  if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
@@ -1407,7 +1411,7 @@ extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void
 }
 
 extern "C" int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream) {
-  if (!d || n < 1 || n > 4) return PG_ERR_ARG;
+  if (!d || n < 1 || n > GROUP_MAX) return PG_ERR_ARG;
   GemmArgsG a;
   bool together = g_gemm_path != 0 && g_gemm_group != 0 && n >= 2;
   long tiles = 0;
@@ -1425,8 +1429,8 @@ extern "C" int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream) {
     tiles += (long)a.gx[i] * a.gy[i];
     flops += 2.0 * di->M * di->N * ((double)di->K + di->K2);
   }
-  for (int i = n; i < 4; ++i) { a.p[i] = a.p[0]; a.gx[i] = a.gy[i] = 1; a.first[i] = 0x7fffffff; }
-  a.first[4] = 0x7fffffff;
+  for (int i = n; i < GROUP_MAX; ++i) { a.p[i] = a.p[0]; a.gx[i] = a.gy[i] = 1; a.first[i] = 0x7fffffff; }
+  a.first[GROUP_MAX] = 0x7fffffff;
   // worth it only if the 256x256 tiles of all products together occupy most of the chip
   const int cus = device_cus();
   together = together && tiles * 2 >= cus && tiles <= 0x7fffffff / 2;

@@ -610,3 +610,49 @@ def test_full_size_stacked_fill_bf16(pg, full_params):
                                  keep_percent=0.3, current_rate=rate, noise=ns.view(rows * W, V))
         for p, w, (a, b) in zip(parts, widths, spans):
             assert torch.equal(st[a:b, :w], p)
+
+
+def test_weight_gradients_of_four_layers_in_one_launch(pg):
+    """bf16 critic update at ProtBERT's layer width (6 layers: one group of four, one of two): the backward
+    passes that launch the weight gradients of four layers together (operands of the waiting layers kept in
+    separate buffer sets) against the same passes launching layer by layer.  The tiles compute the same
+    sums in the same order either way, so the weight gradients are identical; bias and LayerNorm gradients
+    are accumulated atomically and may differ in the last bits."""
+    from protgen_gan_amd import train as T
+    from protgen_gan_amd._lib import lib
+    cfg = pg.ProtBertConfig(num_hidden_layers=6, max_position_embeddings=128)
+    critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=torch.bfloat16).init_random(seed=3))
+    critic.protbert.enable_layer_events()
+    g = torch.Generator().manual_seed(12)
+    B, S = 3, 64
+    real = torch.randint(5, 25, (B, S), generator=g).to(DEV)
+    fake = torch.randint(5, 25, (B, S), generator=g).to(DEV)
+    rm = torch.ones(B, S, device=DEV)
+    rm[1, 50:] = 0
+    alpha = torch.rand(B, 1, 1, generator=g).to(DEV)
+
+    class NoStep:
+        def zero_grad(self):
+            critic.zero_grad(set_to_none=True)
+
+        def step(self):
+            pass
+
+    out = {}
+    try:
+        for depth in (1, 0, 3):  # 0 = by tile count (four layers at this width)
+            assert lib.pg_tune(13, depth) == 0
+            T.critic_update(critic, NoStep(), real, rm, fake, T.GanHyper(lambda_gp=5.0), alpha=alpha)
+            torch.cuda.synchronize()
+            out[depth] = {n: p.grad.clone() for n, p in critic.named_parameters() if p.grad is not None}
+    finally:
+        lib.pg_tune(13, 0)
+    assert len(out[1]) > 90
+    for depth in (0, 3):
+        for n, ref in out[1].items():
+            got = out[depth][n]
+            if n.endswith("weight") and ref.dim() == 2 and "embeddings" not in n and "classifier" not in n:
+                assert torch.equal(got, ref), (depth, n)
+            else:
+                err = float((got - ref).abs().max())
+                assert err <= 1e-4 * float(ref.abs().max()) + 1e-7, (depth, n, err)
