@@ -114,6 +114,8 @@ class GradSync:
         self.overlap = overlap
         self._side = None
         self._tail = None
+        self._plan_cache = None
+        self._layer_spans = None
         if overlap is not None:
             if not any(st is overlap.store for st in self.stores):
                 raise ValueError("overlap model's store is not among the stores to reduce")
@@ -127,22 +129,29 @@ class GradSync:
 
     def _plan(self):
         """[(layer or None, store, lo, hi)] in issue order: layers last to first, then everything else."""
+        lives = [live_ranges(store) if store.grad is not None else None for store in self.stores]
+        key = tuple(tuple(x) if x is not None else None for x in lives)
+        if self._plan_cache is not None and self._plan_cache[0] == key:
+            return self._plan_cache[1]
         plan = []
         rest = []
-        for store in self.stores:
-            if store.grad is None:
+        for store, live in zip(self.stores, lives):
+            if live is None:
                 continue
-            live = live_ranges(store)
             if self.overlap is not None and store is self.overlap.store:
+                if self._layer_spans is None:
+                    L = self.overlap.config.num_hidden_layers
+                    self._layer_spans = [self.overlap.layer_param_range(l) for l in range(L)]
                 spans = []
-                for l in reversed(range(self.overlap.config.num_hidden_layers)):
-                    lo, hi = self.overlap.layer_param_range(l)
+                for l in reversed(range(len(self._layer_spans))):
+                    lo, hi = self._layer_spans[l]
                     spans.append((lo, hi))
                     for a, b in bucket_ranges(clip_ranges(live, lo, hi), self.bucket_elems):
                         plan.append((l, store, a, b))
                 live = cut_ranges(live, sorted(spans))
             for a, b in bucket_ranges(live, self.bucket_elems):
                 rest.append((None, store, a, b))
+        self._plan_cache = (key, plan + rest)
         return plan + rest
 
     def __call__(self):
