@@ -248,6 +248,16 @@ def attention_fwd(qkv, mask, B, S, heads):
     return ctx
 
 
+def attention_fwd_packed(qkv, mask, seq_off, max_len, heads):
+    """As attention_fwd over sequences of different lengths laid back to back: qkv [T, 3*heads*64],
+    mask [T] fp32 or None, seq_off int32 [nseq+1] on the device."""
+    ctx = torch.empty(qkv.shape[0], heads * 64, dtype=qkv.dtype, device=qkv.device)
+    check(lib.pg_attention_fwd_packed(dt_code(qkv.dtype), qkv.data_ptr(), ptr(mask), ctx.data_ptr(), seq_off.data_ptr(),
+                                      seq_off.numel() - 1, max_len, heads, qkv.stride(0), ctx.stride(0), stream()),
+          "pg_attention_fwd_packed")
+    return ctx
+
+
 def attention_bwd_dq(qkv, P, ctx, dctx, B, S, heads):
     """First half of the attention backward over stored P: returns (dS [B*heads,S,ld], dq [B*S,H])."""
     H = heads * 64

@@ -404,6 +404,68 @@ def test_softmax_family(pg, dtype, S):
         assert float(Sbar[:, :, S:].float().abs().max()) == 0.0
 
 
+def test_fused_attention_forward_packed_rows(pg):
+    """Sequences of different lengths laid back to back (1, a few, one query tile, several tiles, not
+    multiples of anything) against eager attention per sequence in fp64; the grid is sized for the longest,
+    the query tiles beyond a shorter sequence's end leave without touching memory."""
+    g = torch.Generator().manual_seed(77)
+    nh = 3
+    H = nh * 64
+    lens = [1, 7, 128, 130, 333, 64, 497]
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    T = off[-1]
+    qkv = rnd(T, 3 * H, dtype=torch.bfloat16, gen=g)
+    qkv[:, :H] *= 2.0
+    mask = (torch.rand(T, generator=g) > 0.2).float()
+    mask[off[3]:off[4]] = 1.0  # one sequence fully visible
+    canary = 12288.0  # representable in bf16
+    for m in (mask, None):
+        ref = torch.empty(T, H, dtype=torch.float64)
+        for a, b in zip(off, off[1:]):
+            q, k, v = (qkv[a:b, i * H:(i + 1) * H].double().view(b - a, nh, 64).transpose(0, 1) for i in range(3))
+            sc = q @ k.transpose(1, 2) * 0.125
+            if m is not None:
+                sc = sc + O.extended_mask(m[a:b].view(1, -1), torch.float64).view(1, 1, -1)
+            ref[a:b] = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(b - a, H)
+        out = pg.ops.attention_fwd_packed(qkv.to(torch.bfloat16).to(DEV), None if m is None else m.to(DEV),
+                                          torch.tensor(off, dtype=torch.int32, device=DEV), max(lens), nh)
+        close(out, ref, torch.bfloat16)
+    # rows after the last sequence are not written
+    pad = torch.full((T + 64, 3 * H), 0.5, dtype=torch.bfloat16)
+    pad[:T] = qkv
+    big = pad.to(DEV)
+    ctx = torch.full((T + 64, H), canary, dtype=torch.bfloat16, device=DEV)
+    from protgen_gan_amd._lib import check, lib
+    so = torch.tensor(off, dtype=torch.int32, device=DEV)
+    check(lib.pg_attention_fwd_packed(1, big.data_ptr(), None, ctx.data_ptr(), so.data_ptr(), len(lens), max(lens), nh,
+                                      big.stride(0), ctx.stride(0), pg.ops.stream()), "pg_attention_fwd_packed")
+    assert bool((ctx[T:].float() == canary).all()) and bool((ctx[:T].float() != canary).all())
+
+
+def test_embed_ln_packed_positions(pg):
+    """Embedding + LayerNorm with explicit positions equals the rectangular kernel on the same (id, position) pairs."""
+    from protgen_gan_amd._lib import check, lib
+    g = torch.Generator().manual_seed(78)
+    B, S, Hd, V, P = 3, 20, 128, 30, 64
+    word, pos, typ = rnd(V, Hd, gen=g).to(DEV), rnd(P, Hd, gen=g).to(DEV), rnd(2, Hd, gen=g).to(DEV)
+    gam, bet = (1 + 0.1 * rnd(Hd, gen=g)).to(DEV), rnd(Hd, gen=g).to(DEV)
+    ids = torch.randint(0, V, (B, S), generator=g).to(DEV)
+    dense = torch.empty(B, S, Hd, dtype=torch.bfloat16, device=DEV)
+    check(lib.pg_embed_ln2(1, ids.data_ptr(), word.data_ptr(), pos.data_ptr(), typ.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                           1e-12, dense.data_ptr(), None, B, S, Hd, pg.ops.stream()), "pg_embed_ln2")
+    widths = [20, 11, 3]
+    idx = torch.cat([torch.arange(w) + b * S for b, w in enumerate(widths)]).to(DEV)
+    pid = torch.cat([torch.arange(w) for w in widths]).to(torch.int32).to(DEV)
+    packed = torch.empty(idx.numel(), Hd, dtype=torch.bfloat16, device=DEV)
+    ids_p = ids.view(-1)[idx].contiguous()
+    check(lib.pg_embed_ln_packed(1, ids_p.data_ptr(), pid.data_ptr(), word.data_ptr(), pos.data_ptr(), typ.data_ptr(),
+                                 gam.data_ptr(), bet.data_ptr(), 1e-12, packed.data_ptr(), idx.numel(), Hd, pg.ops.stream()),
+          "pg_embed_ln_packed")
+    assert torch.equal(packed, dense.view(B * S, Hd)[idx])
+
+
 @pytest.mark.parametrize("S", [40, 64, 200, 512, 497])
 def test_fused_attention_forward(pg, S):
     """Flash-style forward vs eager attention (HF eager_attention_forward) in fp64 on the same
