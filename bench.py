@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--lambda-gp", type=float, default=5.0)
     ap.add_argument("--layers", type=int, default=30, help="(debug only) fewer layers invalidates the number")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--regime", choices=["unfrozen", "frozen"], default="unfrozen",
+                    help="frozen = epoch 0 of the trainers: both ProtBERTs frozen, only the critic head learns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-sample", type=int, default=16)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -84,6 +86,9 @@ def main():
     generator = pg.Generator(pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=dtype).init_random(seed=0))
     torch.manual_seed(2)
     critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=dev, compute_dtype=dtype).init_random(seed=1))
+    if args.regime == "frozen":
+        pgt.freeze_protbert(generator)
+        pgt.freeze_protbert(critic)
     hp = pgt.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.seq, gen_batch_blind=args.gen_batch)
     gen_opt = pg.AdamW(generator.parameters(), lr=5e-6, betas=(0.9, 0.999), weight_decay=0.01)
     critic_opt = pg.AdamW(critic.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
@@ -151,8 +156,11 @@ def main():
 
     # algorithmic FLOPs of the timed region on this rank
     fill_flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
-    critic_flops = args.steps * args.n_critic * 12 * f_c(args.batch, args.seq)
-    gen_flops = args.steps * 3 * f_c(args.gen_batch, args.seq)
+    # forward-equivalents per critic update: unfrozen 12 (penalty 6 + real/fake forward 2 and backward 4);
+    # frozen 5 (penalty forward, input gradient and tangent pass + real/fake forward; no encoder backward)
+    fe_critic, fe_gen = (12, 3) if args.regime == "unfrozen" else (5, 1)
+    critic_flops = args.steps * args.n_critic * fe_critic * f_c(args.batch, args.seq)
+    gen_flops = args.steps * fe_gen * f_c(args.gen_batch, args.seq)
     flops_step = (fill_flops + critic_flops + gen_flops) / args.steps
     ms_step = dt / args.steps * 1e3
 
@@ -181,7 +189,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head",
                    "critic_batch": args.batch, "generator_batch": args.gen_batch, "seq_len": args.seq, "n_critic": args.n_critic,
-                   "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": "unfrozen",
+                   "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime,
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
                    "weights": "ProtBERT architecture, seeded random init", "lengths": "uniform 200..500 (DNMT-length stand-in)"},
         "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
