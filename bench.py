@@ -187,11 +187,13 @@ def main():
         "value": round(world * args.steps / dt, 5), "unit": "GAN steps/s (n_critic=8 critic updates + 1 generator update; summed over ranks)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head",
+        "config": {"workload": ("configs[1]" if (args.batch, args.gen_batch, args.seq, args.n_critic, args.layers) == (8, 4, 512, 8, 30)
+                                else "configs[1] at other sizes") +
+                               ": one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head",
                    "critic_batch": args.batch, "generator_batch": args.gen_batch, "seq_len": args.seq, "n_critic": args.n_critic,
                    "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime,
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
-                   "weights": "ProtBERT architecture, seeded random init", "lengths": "uniform 200..500 (DNMT-length stand-in)"},
+                   "weights": "ProtBERT architecture, seeded random init", "lengths": f"uniform {pool[0]}..{pool[-1]} (DNMT-length stand-in)"},
         "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
         "step_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 2),
         "step_mfma_frac": round(flops_step / (dt / args.steps) / MFMA_PEAK_BF16, 4),
