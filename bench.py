@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--lambda-gp", type=float, default=5.0)
     ap.add_argument("--layers", type=int, default=30, help="(debug only) fewer layers invalidates the number")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--gan-mode", choices=["blind", "seeded"], default="blind",
+                    help="seeded = 10p_train.py's loop: fakes start from real sequences with 90 %% of the residues masked")
     ap.add_argument("--regime", choices=["unfrozen", "frozen"], default="unfrozen",
                     help="frozen = epoch 0 of the trainers: both ProtBERTs frozen, only the critic head learns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +120,15 @@ def main():
                             position_rows=args.seq)
         use_sync = True
 
+    seeds = None
+    if args.gan_mode == "seeded":
+        seeds = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic + 1)]
+                 for _ in range(total)]
+
     def one_step(i):
+        if seeds is not None:
+            return pgt.gan_step_seeded(generator, critic, gen_opt, critic_opt, real[i], seeds[i], hp,
+                                       grad_sync=sync if use_sync else None)
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
                                   grad_sync=sync if use_sync else None)
 
@@ -160,7 +170,7 @@ def main():
     # frozen 5 (penalty forward, input gradient and tangent pass + real/fake forward; no encoder backward)
     fe_critic, fe_gen = (12, 3) if args.regime == "unfrozen" else (5, 1)
     critic_flops = args.steps * args.n_critic * fe_critic * f_c(args.batch, args.seq)
-    gen_flops = args.steps * fe_gen * f_c(args.gen_batch, args.seq)
+    gen_flops = args.steps * fe_gen * f_c(args.gen_batch if seeds is None else args.batch, args.seq)
     flops_step = (fill_flops + critic_flops + gen_flops) / args.steps
     ms_step = dt / args.steps * 1e3
 
@@ -184,13 +194,15 @@ def main():
 
     out = {
         "metric": "ProtBERT GAN train steps/s (gen+critic) & generated seqs/s, 1/2/4/8 GPUs",
-        "value": round(world * args.steps / dt, 5), "unit": "GAN steps/s (n_critic=8 critic updates + 1 generator update; summed over ranks)",
+        "value": round(world * args.steps / dt, 5), "unit": f"GAN steps/s (n_critic={args.n_critic} critic updates + 1 generator update; summed over ranks)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("configs[1]" if (args.batch, args.gen_batch, args.seq, args.n_critic, args.layers) == (8, 4, 512, 8, 30)
-                                else "configs[1] at other sizes") +
-                               ": one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head",
-                   "critic_batch": args.batch, "generator_batch": args.gen_batch, "seq_len": args.seq, "n_critic": args.n_critic,
+        "config": {"workload": ("configs[2] on one GPU: one seeded-mode GAN step (10p_train.py), 90 % of the residues masked"
+                                if seeds is not None else
+                                ("configs[1]" if (args.batch, args.gen_batch, args.seq, args.n_critic, args.layers) == (8, 4, 512, 8, 30)
+                                 else "configs[1] at other sizes") +
+                                ": one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head"),
+                   "critic_batch": args.batch, "generator_batch": args.gen_batch if seeds is None else args.batch, "seq_len": args.seq, "n_critic": args.n_critic,
                    "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime,
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
                    "weights": "ProtBERT architecture, seeded random init", "lengths": f"uniform {pool[0]}..{pool[-1]} (DNMT-length stand-in)"},

@@ -96,6 +96,53 @@ def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: 
     return ids
 
 
+def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tensor], hp: GanHyper, mask_id=4, cls_id=2,
+                               sep_id=3, pad_id=0, unk_id=1, packed: bool = True) -> List[torch.Tensor]:
+    """Seeded-mode fakes for several real batches at once (the generator does not change between the
+    critic updates of one iteration): every batch is masked as generate_fakes_for_batch masks it (its own
+    device draw for the 90 % mask, its own CPU draw of a temperature per fill iteration, in batch order),
+    then all rows are filled as one stacked batch.  The attention mask is `ids != PAD`, so nothing beyond a
+    row's last non-pad position is ever attended or committed: in bf16 the encoder pass runs on each row's
+    own length only (rows laid back to back), about 30 % fewer token rows at the reference's lengths."""
+    if not inputs:
+        return []
+    S = inputs[0].size(1)
+    if any(x.size(1) != S for x in inputs):
+        raise ValueError("seeded batches must share one padded width")
+    parts, temps_per_batch, spans, r = [], [], [], 0
+    for x in inputs:
+        meaningful = (x != pad_id) & (x != unk_id) & (x != cls_id) & (x != sep_id)
+        random_mask = torch.rand(x.shape, device=x.device) < hp.initial_masking_rate
+        ids = x.clone()
+        ids[meaningful & random_mask] = mask_id
+        parts.append(ids)
+        temps_per_batch.append(fill_temperatures(hp))
+        spans.append((r, r + x.size(0)))
+        r += x.size(0)
+    ids = torch.cat(parts, dim=0).contiguous()
+    packing = None
+    if packed and generator.protbert.compute_dtype == torch.bfloat16:
+        cols = torch.arange(1, S + 1, device=ids.device)
+        widths = ((ids != pad_id) * cols).amax(dim=1).clamp_(min=1).tolist()  # last non-pad position + 1
+        if sum(widths) < ids.numel():
+            packing = RowPacking(widths, S, ids.device)
+    rate, it = hp.initial_masking_rate, 0
+    while rate > 0:
+        attn = (ids != pad_id).long()
+        groups = [(a, b, temps[it]) for (a, b), temps in zip(spans, temps_per_batch)]
+        ids = generator.generate_groups(ids, attn, groups, keep_percent=hp.iteration_fill_rate, current_rate=rate,
+                                        packing=packing)
+        if generator.fill_shapes and generator.fill_shapes[-1] == (ids.size(0), S):
+            # throughput bookkeeping: what the pass had to cover (each row's own length when packed)
+            generator.fill_shapes[-1:] = ([(1, w) for w in packing.widths] if packing is not None
+                                          else [(b - a, S) for a, b in spans])
+        rate = max(0, rate - hp.iteration_fill_rate)
+        it += 1
+        if int(generator.last_counts[:, 1].sum().item()) == 0:
+            break
+    return [ids[a:b].contiguous() for a, b in spans]
+
+
 def fill_temperatures(hp: GanHyper) -> List[float]:
     """The per-iteration temperatures one blind-mode fake batch draws (fully_masked_train.py:223):
     one CPU `torch.rand(1)` per pass of the `while rate > 0` loop, whose length is fixed by the
@@ -232,10 +279,20 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
 
 
 def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
-                    real_batches: List[dict], gen_batches: List[dict], hp: GanHyper, grad_sync=None):
+                    real_batches: List[dict], gen_batches: List[dict], hp: GanHyper, grad_sync=None,
+                    stacked_generation: bool = True):
     """One iteration of the seeded-mode loop (10p_train.py:296-370): needs n_critic critic
-    batches and n_critic + 1 generator batches."""
+    batches and n_critic + 1 generator batches.  With `stacked_generation` the n_critic + 1 fake
+    batches are filled up front as one stacked batch (generate_fakes_for_batches)."""
     c_sum = None
+    if stacked_generation:
+        fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:hp.n_critic + 1]], hp)
+        for batch, fake in zip(real_batches[:hp.n_critic], fakes):
+            c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
+                              grad_sync=grad_sync)
+            c_sum = c if c_sum is None else c_sum + c
+        g = generator_update(critic, gen_optimizer, fakes[hp.n_critic])
+        return c_sum / hp.n_critic, g
     for batch, gb in zip(real_batches[:hp.n_critic], gen_batches[:hp.n_critic]):
         fake = generate_fakes_for_batch(generator, gb["input_ids"], hp)
         c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,

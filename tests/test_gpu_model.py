@@ -430,6 +430,65 @@ def test_packed_fill_matches_rectangular(pg, name, widths):
     assert bool((b[~inside] == O.PAD).all())
 
 
+def _real_rows(lengths, width, gen):
+    ids = torch.full((len(lengths), width), O.PAD, dtype=torch.long)
+    for i, L in enumerate(lengths):
+        ids[i, 1:L - 1] = torch.randint(5, 25, (L - 2,), generator=gen)
+        ids[i, 0], ids[i, L - 1] = O.CLS, O.SEP
+    return ids
+
+
+def test_packed_fill_per_row_lengths_pad_mask(pg):
+    """Seeded-mode rule (attention mask = ids != PAD): rows of different lengths, each packed to its own
+    length, against the rectangular pass on the same draws: the same tokens and counts, pads untouched."""
+    from protgen_gan_amd.models import RowPacking
+    c, P, PC, C, gen, critic = build(pg, "mid", torch.bfloat16)
+    V, S = c.vocab_size, 160
+    g = torch.Generator().manual_seed(21)
+    lens = [160, 37, 129, 64, 3, 150, 98]
+    real = _real_rows(lens, S, g)
+    meaningful = (real != O.PAD) & (real != O.CLS) & (real != O.SEP)
+    ids0 = real.clone()
+    ids0[meaningful & (torch.rand(real.shape, generator=g) < 0.9)] = O.MASK
+    ids0 = ids0.to(DEV)
+    pk = RowPacking(lens, S, DEV)
+    groups = [(0, 3, 0.9), (3, 7, 1.1)]
+    a, b = ids0.clone(), ids0.clone()
+    for rate in (0.9, 0.5, 0.1):
+        ns = torch.empty(len(lens) * S, V).exponential_(1.0, generator=g)
+        a = gen.generate_groups(a, (a != O.PAD).long(), groups, keep_percent=0.3, current_rate=rate, noise=ns)
+        ca = gen.last_counts.clone()
+        b = gen.generate_groups(b, (b != O.PAD).long(), groups, keep_percent=0.3, current_rate=rate, noise=ns, packing=pk)
+        assert torch.equal(gen.last_counts, ca)
+        assert torch.equal(a, b), f"rate {rate}: {int((a != b).sum())} tokens differ"
+    keep = (ids0 != O.MASK)
+    assert torch.equal(b[keep], ids0[keep])  # nothing but masked positions changed
+
+
+def test_seeded_fakes_stacked(pg):
+    """generate_fakes_for_batches: every batch keeps its unmasked tokens and its pads, no mask survives the
+    schedule, and a seeded-mode GAN step runs on the stacked fakes (bf16 packed and fp32 rectangular)."""
+    from protgen_gan_amd import train as T
+    for dtype in (torch.bfloat16, torch.float32):
+        c, P, PC, C, gen, critic = build(pg, "tiny", dtype)
+        g = torch.Generator().manual_seed(31)
+        hp = T.GanHyper(max_len=48, n_critic=2)
+        batches = [_real_rows(ls, 48, g).to(DEV) for ls in ([48, 20, 33], [12, 40, 41], [30, 30, 9])]
+        torch.manual_seed(5)
+        fakes = T.generate_fakes_for_batches(gen, batches, hp)
+        assert len(fakes) == 3
+        for x, f in zip(batches, fakes):
+            assert f.shape == x.shape
+            fixed = (x == O.PAD) | (x == O.CLS) | (x == O.SEP)
+            assert torch.equal(f[fixed], x[fixed])
+            assert float((f == x).float().mean()) > 0.1  # the 10 % never masked, at least
+        opt = pg.AdamW(critic.parameters(), lr=1e-4)
+        gopt = pg.AdamW(gen.parameters(), lr=1e-5)
+        mk = lambda x: {"input_ids": x, "attention_mask": (x != O.PAD).long()}  # noqa: E731
+        c_l, g_l = T.gan_step_seeded(gen, critic, gopt, opt, [mk(x) for x in batches[:2]], [mk(x) for x in batches], hp)
+        assert torch.isfinite(c_l).all() and torch.isfinite(g_l).all()
+
+
 def test_stacked_blind_generation_shapes(pg):
     from protgen_gan_amd import train as T
     c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
