@@ -310,22 +310,29 @@ int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const 
  * event l is recorded on `stream` once every launch that adds into layer l's parameter gradients
  * has been issued (layers finish from the last to the first), so that a data-parallel caller can
  * start reducing a layer's gradients on another stream while the pass goes on.  The reference
- * trains on one GPU and has no counterpart.                                               */
+ * trains on one GPU and has no counterpart.
+ * stash_rows / stash_row0 (also on pg_encoder_jvp and pg_encoder_backward2; 0, 0 = the stash is this pass's
+ * own): the primal stash was written by one pg_encoder_forward over stash_rows >= B sequences (several
+ * batches through the encoder together: the gradient-penalty interpolates with the real and fake rows of
+ * fully_masked_train.py:315-323) and this pass works on the B sequences from sequence stash_row0 on.  The
+ * adjoint and tangent stashes always hold exactly this pass's B sequences.                 */
 #define PG_BWD_PARAM_GRADS 1
 #define PG_BWD_SAVE_ADJOINTS 2
 int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                         void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
-                        void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done);
+                        void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
+                        int stash_rows, int stash_row0);
 /* GP tangent-forward pass: xdot_in [B,S,H] -> hdot_out [B,S,H]; writes the tangent stash. */
 int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                    const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
-                   void* stream);
+                   void* stream, int stash_rows, int stash_row0);
 /* GP second-order reverse over (primal stash, adjoint stash, tangent stash): accumulates
  * d<v, ds/dx>/dtheta into p->grad (flags bit0; any loss weight is folded into v by
  * pg_gp_direction) and writes the gradient w.r.t. the encoder input x to xbar_out (nullable). */
 int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                          const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
-                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done);
+                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
+                         int stash_rows, int stash_row0);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,33 @@ Slots layer_slots(char* base, const StashLayout& sl, const Dims& d, int l) {
   return s;
 }
 
+// The primal stash of a pass may have been written by one forward over more sequences than the pass works on
+// (several batches pushed through the encoder together): `rows` sequences laid out, this pass's B sequences
+// start at sequence `row0`.  Every slot is sequence-major, so the view is the slot plus an offset.
+struct StashView {
+  Dims dl;
+  StashLayout sl;
+  long row0;
+};
+bool make_view(const pg_model_cfg* cfg, int dtype, int B, int S, int stash_rows, int stash_row0, StashView& v) {
+  const int rows = stash_rows > 0 ? stash_rows : B;
+  if (stash_row0 < 0 || stash_row0 + B > rows) return false;
+  if (!make_dims(cfg, dtype, rows, S, v.dl)) return false;
+  v.sl = stash_layout(v.dl);
+  v.row0 = stash_row0;
+  return true;
+}
+Slots view_slots(char* base, const StashView& v, int l) {
+  Slots s = layer_slots(base, v.sl, v.dl, l);
+  const Dims& d = v.dl;
+  const long t = v.row0 * d.S * d.es;
+  s.x += t * d.H; s.y += t * d.H; s.ctx += t * d.H; s.a += t * d.H; s.h += t * d.H; s.f += t * d.H;
+  s.qkv += t * 3 * d.H;
+  s.u += t * d.I; s.gu += t * d.I;
+  s.ss += v.row0 * d.nh * d.S * d.ldS * d.es;
+  return s;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ parameter layout
@@ -428,10 +455,13 @@ extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dt
 // ------------------------------------------------------------------ first-order backward
 extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                    void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
-                                   void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done) {
+                                   void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
+                                   int stash_rows, int stash_row0) {
   (void)mask;
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
+  StashView sv;
+  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS, save = flags & PG_BWD_SAVE_ADJOINTS;
   if (grads && !p->grad) return PG_ERR_ARG;
   if (save && !adj_stash) return PG_ERR_ARG;
@@ -455,7 +485,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
   DwQueue dwq;
   dwq.st = st; dwq.done = layer_done; dwq.depth = grads ? dw_depth(d, dtype) : 1;
   for (int l = d.L - 1; l >= 0; --l) {
-    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    const Slots s = view_slots((char*)const_cast<void*>(stash), sv, l);
     Slots a;  // adjoint buffers of this layer
     if (save) {
       a = layer_slots((char*)adj_stash, sl, d, l);
@@ -525,9 +555,11 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
 // ------------------------------------------------------------------ GP tangent-forward pass
 extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                               const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
-                              void* stream) {
+                              void* stream, int stash_rows, int stash_row0) {
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !xdot_in || !tan_stash || !workspace) return PG_ERR_ARG;
+  StashView sv;
+  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   Workspace w = ws_layout(d, (char*)workspace);
   if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
@@ -540,7 +572,7 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
   if (hipMemcpyAsync((char*)tan_stash + sl.xs, xdot_in, th_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return PG_ERR_LAUNCH;
   for (int l = 0; l < d.L; ++l) {
-    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    const Slots s = view_slots((char*)const_cast<void*>(stash), sv, l);
     const Slots t = layer_slots((char*)tan_stash, sl, d, l);
     CK(g.run(t.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, t.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f));
     if (fused_gp_attention(dtype, S)) {
@@ -576,9 +608,12 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
 // ------------------------------------------------------------------ GP second-order reverse pass
 extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                     const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
-                                    void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done) {
+                                    void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
+                                    int stash_rows, int stash_row0) {
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
+  StashView sv;
+  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS;
   if (grads && !p->grad) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
@@ -597,7 +632,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
   DwQueue dwq;
   dwq.st = st; dwq.done = layer_done; dwq.depth = grads ? dw_depth(d, dtype) : 1;
   for (int l = d.L - 1; l >= 0; --l) {
-    const Slots s = layer_slots((char*)const_cast<void*>(stash), sl, d, l);
+    const Slots s = view_slots((char*)const_cast<void*>(stash), sv, l);
     const Slots a = layer_slots((char*)const_cast<void*>(adj_stash), sl, d, l);
     const Slots t = layer_slots((char*)const_cast<void*>(tan_stash), sl, d, l);
     char* xbar = (ybar == w.x0) ? w.x1 : w.x0;

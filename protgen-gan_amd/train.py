@@ -10,6 +10,7 @@ Order of random draws follows the reference: Python `random` for sequence length
 `torch.rand(B,1,1)` for the gradient-penalty interpolation (loss.py:15)."""
 from __future__ import annotations
 
+import os
 import random
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -17,8 +18,14 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from . import ops
+from ._lib import check, lib
 from .loss import compute_gradient_penalty, critic_loss, generator_loss
 from .models import Critic, Generator, RowPacking
+
+
+# A/B switch (PG_ONE_FORWARD=0 restores the call-by-call critic update everywhere)
+ONE_FORWARD_DEFAULT = os.environ.get("PG_ONE_FORWARD", "1") != "0"
 
 
 @dataclass
@@ -204,14 +211,114 @@ def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequ
     return out
 
 
+def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask_real, fake, fake_mask, hp: GanHyper,
+                               grad_sync, alpha) -> torch.Tensor:
+    """The critic update with ONE encoder forward over 3B sequences: the gradient-penalty interpolates
+    (loss.py:22-66) and the real and fake rows (fully_masked_train.py:321-323) use the same weights, and at
+    B = 8 a forward over 4096 or 8192 token rows runs at little more than half the rate of one over 12 288.
+    Everything after the forward is what `compute_gradient_penalty` + `critic(...)` + `c_loss.backward()` do,
+    issued by hand on views of the shared stash: input-gradient pass and penalty on the first B sequences,
+    score backward on the other 2B, tangent and second-order passes on the first B."""
+    m, head = critic.protbert, critic.classifier
+    B, S = real.shape
+    H = m.config.hidden_size
+    cd = m.compute_dtype
+    dt = ops.dt_code(cd)
+    st = ops.stream()
+    dev = real.device
+    lam = float(hp.lambda_gp)
+    critic_optimizer.zero_grad()
+    if alpha is None:
+        alpha = torch.rand(B, 1, 1)
+    alpha = alpha.to(device=dev, dtype=torch.float32).contiguous().view(B)
+    rmask = attn_mask_real.to(dev)
+    joint = (rmask.bool() & fake_mask.bool()).to(torch.float32)
+    mask3 = torch.cat([joint, rmask.to(torch.float32), fake_mask.to(torch.float32)], dim=0).contiguous()
+
+    # embeddings of both batches straight into their rows of the 3B input, interpolates into the first B
+    X = torch.empty(3 * B, S, H, dtype=cd, device=dev)
+    sum_r = torch.empty(B, S, H, dtype=cd, device=dev)
+    sum_f = torch.empty_like(sum_r)
+    m._embed(real, X[B:2 * B], sum_r)
+    m._embed(fake, X[2 * B:], sum_f)
+    check(lib.pg_interpolate(dt, X[B:2 * B].data_ptr(), X[2 * B:].data_ptr(), alpha.data_ptr(), X[:B].data_ptr(), B, S * H, st),
+          "pg_interpolate")
+    hidden, stash = m._encode(None, X, mask3, want_stash=True)
+    del X
+    scores = torch.empty(3 * B, 1, dtype=torch.float32, device=dev)
+    hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
+    check(lib.pg_head_forward(dt, hidden.data_ptr(), S * H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
+                              hstash.data_ptr(), st), "pg_head_forward")
+    # penalty: g = d sum(scores of the interpolates) / dx, keeping every layer's adjoints
+    dh = torch.zeros(B, S, H, dtype=cd, device=dev)
+    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dh.data_ptr(), S * H, st),
+          "pg_head_backward")
+    adj = m._new_stash(B, S)
+    g = m._encode_backward(stash, dh, B, S, param_grads=False, adj_stash=adj, stash_rows=3 * B, row0=0)
+    norms = torch.empty(B, dtype=torch.float32, device=dev)
+    gp = torch.empty((), dtype=torch.float32, device=dev)
+    joint = joint.contiguous()
+    check(lib.pg_gp_norms(dt, g.data_ptr(), joint.data_ptr(), B, S, H, norms.data_ptr(), gp.data_ptr(), st), "pg_gp_norms")
+    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
+
+    # ---- backward of c_loss = -mean(real) + mean(fake) + lam * gp
+    m.store.begin_accumulate()
+    head.store.begin_accumulate()
+    ghead = head.store.grad
+    w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
+    dh2 = torch.zeros(2 * B, S, H, dtype=cd, device=dev)
+    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                               ghead.data_ptr(), dh2.data_ptr(), S * H, st), "pg_head_backward")
+    dx2 = m._encode_backward(stash, dh2, 2 * B, S, param_grads=True, stash_rows=3 * B, row0=B)
+    m._embed_backward(real, sum_r, dx2[:B])
+    m._embed_backward(fake, sum_f, dx2[B:])
+    # penalty direction, tangent pass, second-order pass (loss.py's create_graph backward)
+    scale = torch.full((), lam, dtype=torch.float32, device=dev)
+    v = torch.empty_like(g)
+    check(lib.pg_gp_direction(dt, g.data_ptr(), joint.data_ptr(), norms.data_ptr(), B, S, H, scale.data_ptr(), v.data_ptr(),
+                              None, st), "pg_gp_direction")
+    tan = m._new_stash(B, S)
+    hdot = m._encode_jvp(stash, v, B, S, tan, stash_rows=3 * B, row0=0)
+    tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
+    check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot.data_ptr(), S * H, B, H, 1.0,
+                               ghead.data_ptr(), tstash.data_ptr(), None, st), "pg_head_jvp_grad")
+    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0)
+    d_r = torch.empty_like(xbar)
+    d_f = torch.empty_like(xbar)
+    check(lib.pg_interpolate_bwd(dt, xbar.data_ptr(), alpha.data_ptr(), d_r.data_ptr(), d_f.data_ptr(), B, S * H, st),
+          "pg_interpolate_bwd")
+    m._embed_backward(real, sum_r, d_r)
+    m._embed_backward(fake, sum_f, d_f)
+    if grad_sync is not None:
+        grad_sync()
+    critic_optimizer.step()
+    return c_loss.detach()
+
+
 def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, fake_data, hp: GanHyper,
-                  pad_id=0, grad_sync: Optional[Callable[[], None]] = None, alpha=None) -> torch.Tensor:
+                  pad_id=0, grad_sync: Optional[Callable[[], None]] = None, alpha=None,
+                  one_forward: Optional[bool] = None) -> torch.Tensor:
     """fully_masked_train.py:297-326 / 10p_train.py:327-338.  `grad_sync` (data-parallel
     gradient averaging) runs between backward and the optimizer step.  Returns c_loss
-    (device scalar; the caller decides when to synchronise for logging)."""
-    critic_optimizer.zero_grad()
+    (device scalar; the caller decides when to synchronise for logging).
+
+    `one_forward` (default: whenever every critic parameter trains): interpolates, real and fake rows
+    share one encoder forward, see _critic_update_one_forward; False = the reference's sequence of calls
+    through autograd."""
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
+    trainable = critic.protbert.encoder_trainable() and critic.classifier[0].weight.requires_grad
+    if one_forward is None:
+        one_forward = trainable and ONE_FORWARD_DEFAULT
+    if one_forward:
+        if not trainable:
+            raise ValueError("one_forward needs the encoder and the head trainable")
+        real = critic.protbert._check_ids(real_data)
+        fk = critic.protbert._check_ids(fake)
+        if real.shape != fk.shape:
+            raise ValueError(f"real {tuple(real.shape)} and fake {tuple(fk.shape)} batches differ in shape")
+        return _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha)
+    critic_optimizer.zero_grad()
     gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device, alpha=alpha)
     # real and fake rows go through the encoder as one 2B-row batch (rows are independent, so the
     # scores equal those of two separate calls); the larger GEMMs fill the chip better

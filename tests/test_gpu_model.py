@@ -250,9 +250,12 @@ def test_critic_step_vs_oracle_fresh_inputs(pg):
         rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
 
 
-def test_train_critic_update_matches_oracle(pg):
-    """train.critic_update (real and fake rows batched through the encoder as one 2B-row pass,
-    alpha drawn from the CPU generator as loss.py:15 does) against the oracle's critic step."""
+@pytest.mark.parametrize("one_forward", [True, False])
+def test_train_critic_update_matches_oracle(pg, one_forward):
+    """train.critic_update against the oracle's critic step, alpha drawn from the CPU generator as
+    loss.py:15 does: with one encoder forward over the 3B sequences (interpolates, real, fake) and the
+    passes after it on views of the shared stash, and call by call through autograd (real and fake rows
+    as one 2B-row pass)."""
     from protgen_gan_amd import train as T
     c, P, PC, C, _, critic = build(pg, "tiny", torch.float32)
     g = torch.Generator().manual_seed(78)
@@ -278,7 +281,7 @@ def test_train_critic_update_matches_oracle(pg):
 
     torch.manual_seed(4242)
     d = lambda t: t.to(DEV)  # noqa: E731
-    l_h = T.critic_update(critic, NoStep(), d(real), d(rm), d(fake), T.GanHyper(lambda_gp=5.0))
+    l_h = T.critic_update(critic, NoStep(), d(real), d(rm), d(fake), T.GanHyper(lambda_gp=5.0), one_forward=one_forward)
     rel_close(l_h.item(), loss.numpy(), 2e-4, "loss")
     named = dict(critic.named_parameters())
     gmax = max(float(v.abs().max()) for v in grads.values())
