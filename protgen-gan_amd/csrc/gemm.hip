@@ -1186,6 +1186,7 @@ int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = p
 int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
+int g_gemm_wide_min_tiles = 160;  // fewest 256x256 tiles at which a narrow-N (512 <= N < 2048) product takes the 256x256 kernel
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 
 }  // namespace
@@ -1204,6 +1205,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
   if (key == 11) { g_gemm_group = value; return PG_OK; }
+  if (key == 14) { if (value < 1) return PG_ERR_ARG; g_gemm_wide_min_tiles = value; return PG_OK; }
   if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
@@ -1243,9 +1245,9 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
                               (g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
-                     // narrow N but long K and at least two full rounds of tiles: the halved L2 -> LDS
-                     // traffic outweighs the partial last round
-                     (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= 512));
+                     // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round down to
+                     // 160 tiles (192 tiles on 256 CUs beat 768 tiles of 128x128 by 17 %; at 128 tiles they lose)
+                     (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= g_gemm_wide_min_tiles));
   if (d->K2 > 0 && (!fast || narrow || !g_gemm_dualk)) {
     // only the 128x128 and 256x256 direct-to-LDS kernels walk two reduction segments: elsewhere two launches
     if (d->bias || d->residual || d->act != PG_ACT_NONE) return PG_ERR_UNSUPPORTED;  // the epilogue would apply twice
