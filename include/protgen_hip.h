@@ -315,13 +315,17 @@ int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const 
  * own): the primal stash was written by one pg_encoder_forward over stash_rows >= B sequences (several
  * batches through the encoder together: the gradient-penalty interpolates with the real and fake rows of
  * fully_masked_train.py:315-323) and this pass works on the B sequences from sequence stash_row0 on.  The
- * adjoint and tangent stashes always hold exactly this pass's B sequences.                 */
+ * The tangent stash always holds exactly this pass's B sequences.
+ * grad_row0 (pg_encoder_backward): parameter gradients are accumulated from the sequences grad_row0.. only;
+ * the sequences before them get their input gradient and adjoints (the interpolates of the gradient penalty
+ * in one backward with the real and fake rows).  adj_rows (pg_encoder_backward2; 0 = B): the adjoint stash was
+ * written by such a pass over adj_rows sequences, this pass's B sequences are its first.    */
 #define PG_BWD_PARAM_GRADS 1
 #define PG_BWD_SAVE_ADJOINTS 2
 int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                         void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                        int stash_rows, int stash_row0);
+                        int stash_rows, int stash_row0, int grad_row0);
 /* GP tangent-forward pass: xdot_in [B,S,H] -> hdot_out [B,S,H]; writes the tangent stash. */
 int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                    const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
@@ -332,7 +336,7 @@ int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B
 int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                          const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
                          void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                         int stash_rows, int stash_row0);
+                         int stash_rows, int stash_row0, int adj_rows);
 
 #ifdef __cplusplus
 }

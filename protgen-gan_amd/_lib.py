@@ -106,12 +106,12 @@ SIGNATURES = {
     "pg_stash_bytes": (i64, [cfgp, i32, i32, i32]),
     "pg_encoder_forward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "pg_mlm_logits": (i32, [cfgp, parp, i32, vp, i32, vp, i64, vp, vp]),
-    "pg_encoder_backward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i32, i32]),
+    "pg_encoder_backward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i32, i32, i32]),
     "pg_encoder_forward_packed": (i32, [cfgp, parp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
     "pg_embed_ln_packed": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp]),
     "pg_attention_fwd_packed": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
     "pg_encoder_jvp": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, i32, i32]),
-    "pg_encoder_backward2": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp, vp, i32, i32]),
+    "pg_encoder_backward2": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp, vp, i32, i32, i32]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

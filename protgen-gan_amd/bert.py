@@ -564,7 +564,7 @@ class ProtBertForMaskedLM(nn.Module):
                                             hidden.data_ptr(), ops.stream()), "pg_encoder_forward_packed")
         return hidden
 
-    def _encode_backward(self, stash, dh, B, S, param_grads, adj_stash=None, stash_rows=0, row0=0):
+    def _encode_backward(self, stash, dh, B, S, param_grads, adj_stash=None, stash_rows=0, row0=0, grad_row0=0):
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(B, S)
         flags = (PG_BWD_PARAM_GRADS if param_grads else 0) | (PG_BWD_SAVE_ADJOINTS if adj_stash is not None else 0)
@@ -572,7 +572,7 @@ class ProtBertForMaskedLM(nn.Module):
         pr = _params_struct(self.store, self.compute_dtype, param_grads)
         check(lib.pg_encoder_backward(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), dh.data_ptr(), None,
                                       flags, ops.ptr(adj_stash), dx.data_ptr(), ws.data_ptr(), n, ops.stream(),
-                                      self._layer_event_arr if param_grads else None, stash_rows, row0),
+                                      self._layer_event_arr if param_grads else None, stash_rows, row0, grad_row0),
               "pg_encoder_backward")
         return dx
 
@@ -586,14 +586,14 @@ class ProtBertForMaskedLM(nn.Module):
               "pg_encoder_jvp")
         return hdot
 
-    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0):
+    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0, adj_rows=0):
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(B, S)
         xbar = torch.empty(B, S, self.config.hidden_size, dtype=self.compute_dtype, device=self.device) if want_xbar else None
         pr = _params_struct(self.store, self.compute_dtype, True)
         check(lib.pg_encoder_backward2(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), adj.data_ptr(),
                                        tan.data_ptr(), PG_BWD_PARAM_GRADS, ops.ptr(xbar), ws.data_ptr(), n, ops.stream(),
-                                       self._layer_event_arr, stash_rows, row0),
+                                       self._layer_event_arr, stash_rows, row0, adj_rows),
               "pg_encoder_backward2")
         return xbar
 

@@ -456,7 +456,7 @@ extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dt
 extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                    void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
                                    void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                                   int stash_rows, int stash_row0) {
+                                   int stash_rows, int stash_row0, int grad_row0) {
   (void)mask;
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
@@ -476,6 +476,19 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
   const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
   StashLayout sl = stash_layout(d);
   const size_t th_bytes = (size_t)d.T * H * es;
+  // parameter gradients are taken from the sequences grad_row0.. only (the others ride along for their input
+  // gradient and adjoints: the gradient-penalty interpolates in front of the real and fake rows)
+  if (grad_row0 < 0 || grad_row0 >= B) return PG_ERR_ARG;
+  const long r0 = (long)grad_row0 * S;
+  const int Tg = T - (int)r0;
+  auto ln_bwd = [&](const char* x, const char* dyp, const float* gamma, char* out, float* gG, float* gB, float* gX) -> int {
+    if (!grads) return pg_layernorm_bwd(dtype, x, dyp, gamma, cfg->ln_eps, out, nullptr, nullptr, nullptr, w.ln_partial, T, H, st);
+    if (r0 == 0) return pg_layernorm_bwd(dtype, x, dyp, gamma, cfg->ln_eps, out, gG, gB, gX, w.ln_partial, T, H, st);
+    const int rc = pg_layernorm_bwd(dtype, x, dyp, gamma, cfg->ln_eps, out, nullptr, nullptr, nullptr, w.ln_partial, (int)r0, H, st);
+    if (rc != PG_OK) return rc;
+    const long o = r0 * H * es;
+    return pg_layernorm_bwd(dtype, x + o, dyp + o, gamma, cfg->ln_eps, out + o, gG, gB, gX, w.ln_partial, Tg, H, st);
+  };
 
   char* dy = (char*)d_hidden;
   if (save) {
@@ -497,9 +510,8 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     if (l == 0 && dx_out && !save) a.x = (char*)dx_out;
     // LN2
     // (the column sums of a LayerNorm backward's output are the bias gradient of the Linear before it)
-    CK(pg_layernorm_bwd(dtype, s.f, dy, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, a.f,
-                        grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,
-                        grads ? pv.g(pv.lo(l, PG_L_B2)) : nullptr, w.ln_partial, T, H, st));
+    CK(ln_bwd(s.f, dy, pv.m(pv.lo(l, PG_L_LN2_G)), a.f, pv.g(pv.lo(l, PG_L_LN2_G)), pv.g(pv.lo(l, PG_L_LN2_B)),
+              pv.g(pv.lo(l, PG_L_B2))));
     // (the four weight gradients of the layer are launched together once dqkv exists: see below)
     // d gu = df W2 ; du = dgu * gelu'(u)
     if (save) {
@@ -509,13 +521,12 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.u, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
                PG_ACT_MUL_DGELU, s.u, I));
     }
-    if (grads) CK(pg_colsum_acc(dtype, a.u, I, T, I, pv.g(pv.lo(l, PG_L_B1)), st));
+    if (grads) CK(pg_colsum_acc(dtype, a.u + r0 * I * es, I, Tg, I, pv.g(pv.lo(l, PG_L_B1)), st));
     // dh = du W1 + df
     CK(g.run(a.u, true, I, pv.w(pv.lo(l, PG_L_W1)), false, H, a.h, dtype, H, T, H, I, 1.f, 0.f, nullptr, a.f, H));
     // LN1
-    CK(pg_layernorm_bwd(dtype, s.a, a.h, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, a.a,
-                        grads ? pv.g(pv.lo(l, PG_L_LN1_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN1_B)) : nullptr,
-                        grads ? pv.g(pv.lo(l, PG_L_BO)) : nullptr, w.ln_partial, T, H, st));
+    CK(ln_bwd(s.a, a.h, pv.m(pv.lo(l, PG_L_LN1_G)), a.a, pv.g(pv.lo(l, PG_L_LN1_G)), pv.g(pv.lo(l, PG_L_LN1_B)),
+              pv.g(pv.lo(l, PG_L_BO))));
     // dctx = da Wo   (dWo = da^T ctx waits for dWqkv below: 64 + 192 tiles fill the chip together)
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
@@ -534,11 +545,12 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
              0.f));
     if (grads) {
       // dW2 = df^T gu, dW1 = du^T h, dWqkv = dqkv^T x, dWo = da^T ctx: 64 + 64 + 48 + 16 tiles of 256x256
-      const pg_gemm_desc dws[4] = {g.dw_desc(a.f, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T),
-                                   g.dw_desc(a.u, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T),
-                                   g.dw_desc(a.qkv, s.x, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, T),
-                                   g.dw_desc(a.a, s.ctx, pv.g(pv.lo(l, PG_L_WO)), H, H, T)};
-      CK(pg_colsum_acc(dtype, a.qkv, 3 * H, T, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
+      const long oH = r0 * H * es, oI = r0 * I * es, oQ = r0 * 3 * H * es;
+      const pg_gemm_desc dws[4] = {g.dw_desc(a.f + oH, s.gu + oI, pv.g(pv.lo(l, PG_L_W2)), H, I, Tg),
+                                   g.dw_desc(a.u + oI, s.h + oH, pv.g(pv.lo(l, PG_L_W1)), I, H, Tg),
+                                   g.dw_desc(a.qkv + oQ, s.x + oH, pv.g(pv.lo(l, PG_L_WQ)), 3 * H, H, Tg),
+                                   g.dw_desc(a.a + oH, s.ctx + oH, pv.g(pv.lo(l, PG_L_WO)), H, H, Tg)};
+      CK(pg_colsum_acc(dtype, a.qkv + oQ, 3 * H, Tg, 3 * H, pv.g(pv.lo(l, PG_L_BQ)), st));
       CK(dwq.push(l, dws));
     }
     // dx = dqkv Wqkv + da
@@ -609,11 +621,12 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
 extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                     const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
                                     void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                                    int stash_rows, int stash_row0) {
+                                    int stash_rows, int stash_row0, int adj_rows) {
   Dims d;
   if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
-  StashView sv;
+  StashView sv, sva;
   if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
+  if (!make_view(cfg, dtype, B, S, adj_rows, 0, sva)) return PG_ERR_ARG;  // adjoints of a pass over adj_rows >= B sequences
   const bool grads = flags & PG_BWD_PARAM_GRADS;
   if (grads && !p->grad) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
@@ -633,7 +646,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
   dwq.st = st; dwq.done = layer_done; dwq.depth = grads ? dw_depth(d, dtype) : 1;
   for (int l = d.L - 1; l >= 0; --l) {
     const Slots s = view_slots((char*)const_cast<void*>(stash), sv, l);
-    const Slots a = layer_slots((char*)const_cast<void*>(adj_stash), sl, d, l);
+    const Slots a = view_slots((char*)const_cast<void*>(adj_stash), sva, l);
     const Slots t = layer_slots((char*)const_cast<void*>(tan_stash), sl, d, l);
     char* xbar = (ybar == w.x0) ? w.x1 : w.x0;
     const int r = (d.L - 1 - l) % dwq.depth;

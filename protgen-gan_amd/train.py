@@ -26,6 +26,8 @@ from .models import Critic, Generator, RowPacking
 
 # A/B switch (PG_ONE_FORWARD=0 restores the call-by-call critic update everywhere)
 ONE_FORWARD_DEFAULT = os.environ.get("PG_ONE_FORWARD", "1") != "0"
+# with one forward: also one first-order backward over the 3B sequences (PG_ONE_BACKWARD=0: two, B and 2B)
+ONE_BACKWARD_DEFAULT = os.environ.get("PG_ONE_BACKWARD", "1") != "0"
 
 
 @dataclass
@@ -249,27 +251,42 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
     check(lib.pg_head_forward(dt, hidden.data_ptr(), S * H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
                               hstash.data_ptr(), st), "pg_head_forward")
-    # penalty: g = d sum(scores of the interpolates) / dx, keeping every layer's adjoints
-    dh = torch.zeros(B, S, H, dtype=cd, device=dev)
-    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dh.data_ptr(), S * H, st),
-          "pg_head_backward")
-    adj = m._new_stash(B, S)
-    g = m._encode_backward(stash, dh, B, S, param_grads=False, adj_stash=adj, stash_rows=3 * B, row0=0)
-    norms = torch.empty(B, dtype=torch.float32, device=dev)
-    gp = torch.empty((), dtype=torch.float32, device=dev)
-    joint = joint.contiguous()
-    check(lib.pg_gp_norms(dt, g.data_ptr(), joint.data_ptr(), B, S, H, norms.data_ptr(), gp.data_ptr(), st), "pg_gp_norms")
-    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
-
-    # ---- backward of c_loss = -mean(real) + mean(fake) + lam * gp
     m.store.begin_accumulate()
     head.store.begin_accumulate()
     ghead = head.store.grad
     w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
-    dh2 = torch.zeros(2 * B, S, H, dtype=cd, device=dev)
-    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
-                               ghead.data_ptr(), dh2.data_ptr(), S * H, st), "pg_head_backward")
-    dx2 = m._encode_backward(stash, dh2, 2 * B, S, param_grads=True, stash_rows=3 * B, row0=B)
+    norms = torch.empty(B, dtype=torch.float32, device=dev)
+    gp = torch.empty((), dtype=torch.float32, device=dev)
+    joint = joint.contiguous()
+    if ONE_BACKWARD_DEFAULT:
+        # ONE first-order backward over the 3B sequences: the interpolates' rows start from the head's unit
+        # backward (g = d sum(scores)/dx, loss.py:68-75) and only leave their input gradient and adjoints, the
+        # real and fake rows start from d c_loss / d scores = -1/B, +1/B and are the only ones whose parameter
+        # gradients are taken (grad_row0 = B)
+        dh3 = torch.zeros(3 * B, S, H, dtype=cd, device=dev)
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dh3.data_ptr(), S * H,
+                                   st), "pg_head_backward")
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                                   ghead.data_ptr(), dh3[B:].data_ptr(), S * H, st), "pg_head_backward")
+        adj = m._new_stash(3 * B, S)
+        adj_rows = 3 * B
+        dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B)
+        g = dx3[:B]
+        dx2 = dx3[B:]
+    else:
+        # penalty: g = d sum(scores of the interpolates) / dx, keeping every layer's adjoints
+        dh = torch.zeros(B, S, H, dtype=cd, device=dev)
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dh.data_ptr(), S * H,
+                                   st), "pg_head_backward")
+        adj = m._new_stash(B, S)
+        adj_rows = 0
+        g = m._encode_backward(stash, dh, B, S, param_grads=False, adj_stash=adj, stash_rows=3 * B, row0=0)
+        dh2 = torch.zeros(2 * B, S, H, dtype=cd, device=dev)
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                                   ghead.data_ptr(), dh2.data_ptr(), S * H, st), "pg_head_backward")
+        dx2 = m._encode_backward(stash, dh2, 2 * B, S, param_grads=True, stash_rows=3 * B, row0=B)
+    check(lib.pg_gp_norms(dt, g.data_ptr(), joint.data_ptr(), B, S, H, norms.data_ptr(), gp.data_ptr(), st), "pg_gp_norms")
+    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
     m._embed_backward(real, sum_r, dx2[:B])
     m._embed_backward(fake, sum_f, dx2[B:])
     # penalty direction, tangent pass, second-order pass (loss.py's create_graph backward)
@@ -282,7 +299,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
     check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot.data_ptr(), S * H, B, H, 1.0,
                                ghead.data_ptr(), tstash.data_ptr(), None, st), "pg_head_jvp_grad")
-    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0)
+    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0, adj_rows=adj_rows)
     d_r = torch.empty_like(xbar)
     d_f = torch.empty_like(xbar)
     check(lib.pg_interpolate_bwd(dt, xbar.data_ptr(), alpha.data_ptr(), d_r.data_ptr(), d_f.data_ptr(), B, S * H, st),
