@@ -198,6 +198,7 @@ struct DwQueue {
   }
 };
 }  // namespace
+int pg_internal_fused_dgelu_save = 1;  // pg_tune key 15: GELU backward in the GEMM epilogue also when adjoints are kept
 int pg_internal_dw_depth = 0;  // 0 = choose by tile count; 1..4 = force (pg_tune key 13)
 namespace {
 // Layers per grouped launch: the count in 1..4 whose tiles fill whole rounds of the 256 CUs best.
@@ -514,12 +515,13 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
               pv.g(pv.lo(l, PG_L_B2))));
     // (the four weight gradients of the layer are launched together once dqkv exists: see below)
     // d gu = df W2 ; du = dgu * gelu'(u)
-    if (save) {
+    if (save && !pg_internal_fused_dgelu_save) {
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.gu, dtype, I, T, I, H, 1.f, 0.f));
       CK(pg_gelu_bwd2(dtype, s.u, nullptr, nullptr, a.gu, a.u, (int64_t)d.T * I, st));
     } else {
+      // (the adjoint of the GELU output, which the second-order pass needs, leaves the same epilogue when adjoints are kept)
       CK(g.run(a.f, true, H, pv.w(pv.lo(l, PG_L_W2)), false, I, a.u, dtype, I, T, I, H, 1.f, 0.f, nullptr, nullptr, 0,
-               PG_ACT_MUL_DGELU, s.u, I));
+               PG_ACT_MUL_DGELU, s.u, I, save ? a.gu : nullptr));
     }
     if (grads) CK(pg_colsum_acc(dtype, a.u + r0 * I * es, I, Tg, I, pv.g(pv.lo(l, PG_L_B1)), st));
     // dh = du W1 + df
