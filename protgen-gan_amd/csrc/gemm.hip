@@ -1278,6 +1278,7 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
       if (d->residual) rest.residual = (const char*)d->residual + rows1 * d->ldr * esz;
       if (d->aux) rest.aux = (char*)d->aux + rows1 * d->ldaux * esz;
       if (d->aux2) rest.aux2 = (char*)d->aux2 + rows1 * d->ldaux * esz;
+      if (d->K2 > 0) rest.A2 = (const char*)d->A2 + rows1 * d->lda * esz;  // second segment: same rows of A2
       const int rc1 = pg_gemm(&top, stream);
       return rc1 != PG_OK ? rc1 : pg_gemm(&rest, stream);
     }

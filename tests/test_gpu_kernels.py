@@ -248,6 +248,30 @@ def test_gemm_wide_tile_split_last_round(pg):
     close(out, K_gelu(ref / 64 + bias.double()), bf)
 
 
+def test_gemm_split_last_round_two_segments(pg):
+    """The same split with a second reduction segment and a k-major A: the rows that go to the second
+    launch must take the same rows of A2.  Exact integers against two plain products."""
+    g = torch.Generator().manual_seed(43)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N, K, K2 = 1024, 1024, 128
+    M = (cus // 4) * 256 + 296  # one full round of 256x256 tiles (N = 4 tiles wide), then a sparse one
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    B = torch.randint(-2, 3, (N, K), generator=g).float()
+    A2 = torch.randint(-2, 3, (M, K2), generator=g).float()
+    B2 = torch.randint(-2, 3, (N, K2), generator=g).float()
+    A2[:, 0] += torch.arange(M) % 5  # rows of the second segment are told apart
+    bf = torch.bfloat16
+    # (A2, B2) share the leading dimensions of (A, B): views into wider buffers
+    A2w = torch.zeros(M, K, dtype=bf)
+    A2w[:, :K2] = A2.to(bf)
+    B2w = torch.zeros(N, K, dtype=bf)
+    B2w[:, :K2] = B2.to(bf)
+    out = pg.ops.gemm(A.to(bf).to(DEV), B.to(bf).to(DEV), out_dtype=torch.float32, A2=A2w.to(DEV)[:, :K2],
+                      B2=B2w.to(DEV)[:, :K2])
+    ref = A.double() @ B.double().T + A2.double() @ B2.double().T
+    assert torch.equal(out.cpu().double(), ref)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [128, 200])
 def test_gemm_group_weight_gradients(pg, dtype, T):
