@@ -27,6 +27,7 @@ extern "C" {
 #define PG_ERR_LAUNCH (-3)
 #define PG_ERR_UNSUPPORTED (-4)
 #define PG_ERR_WORKSPACE (-5)
+#define PG_ERR_SCRATCH (-6) /* beyond the capacity of the library's static device scratch */
 
 #define PG_F32 0
 #define PG_BF16 1
@@ -144,6 +145,14 @@ int pg_layernorm(int dtype, const void* x, const float* gamma, const float* beta
 int pg_ln_partial_rows(int rows);
 int pg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
                      float* dgamma, float* dbeta, float* dxsum, float* partial, int rows, int H, void* stream);
+/* pg_layernorm_bwd without the `partial` argument, for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  The partial sums live in a 12 MiB device array inside the library (one copy per GPU, held
+ * until the process ends); limits: H <= 1024 (PG_ERR_SCRATCH beyond), any row count.  Calls no hipMalloc /
+ * hipFree.  The device of `stream` must be current.  All calls on one GPU share the array, so two calls
+ * that overlap on one GPU (different streams) race; calls on one stream are ordered and safe. */
+int pg_layernorm_bwd_static(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
+                            float* dgamma, float* dbeta, float* dxsum, int rows, int H, void* stream);
 /* Tangent (JVP): ydot = gamma * rstd * Proj(xdot). */
 int pg_layernorm_jvp(int dtype, const void* x, const void* xdot, const float* gamma, float eps, void* ydot,
                      int rows, int H, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pg_layernorm": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp]),
     "pg_ln_partial_rows": (i32, [i32]),
     "pg_layernorm_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "pg_layernorm_bwd_static": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp]),
     "pg_layernorm_jvp": (i32, [i32, vp, vp, vp, f32, vp, i32, i32, vp]),
     "pg_layernorm_bwd2": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "pg_gelu_bwd2": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),

@@ -671,6 +671,7 @@ extern "C" const char* pg_strerror(int code) {
     case PG_ERR_LAUNCH: return "kernel launch failed";
     case PG_ERR_UNSUPPORTED: return "shape not supported by this kernel";
     case PG_ERR_WORKSPACE: return "workspace missing or too small";
+    case PG_ERR_SCRATCH: return "size exceeds the capacity of the library's static device scratch";
     default: return "unknown error";
   }
 }

@@ -595,6 +595,33 @@ extern "C" int pg_layernorm_bwd(int dtype, const void* x, const void* dy, const 
   return ln_bwd_launch<false>(dtype, x, nullptr, dy, nullptr, gamma, eps, dx, dgamma, dbeta, dxsum, partial, rows, H,
                               (hipStream_t)stream);
 }
+// ---- allocation-free LayerNorm backward -----------------------------------------------------
+// Same kernels as pg_layernorm_bwd, with the partial sums in a file-scope device array instead of
+// caller memory.  Every GPU the library runs on holds its own copy of the array (12 MiB) at its
+// own address; the address is looked up once per device and only that pointer is ever handed to
+// launches.  All calls on one GPU share the array: calls that overlap on one GPU race.
+constexpr int LN_STATIC_MAX_H = 1024;
+constexpr int LN_STATIC_ROWS = 1024;  // pg_ln_partial_rows never exceeds this
+static __device__ __align__(256) float ln_static_scratch[3 * LN_STATIC_MAX_H * LN_STATIC_ROWS];
+constexpr int LN_STATIC_MAX_DEVICES = 64;
+static float* g_ln_static_ptr[LN_STATIC_MAX_DEVICES];  // zero-initialised: not looked up yet
+
+extern "C" int pg_layernorm_bwd_static(int dtype, const void* x, const void* dy, const float* gamma, float eps, void* dx,
+                                       float* dgamma, float* dbeta, float* dxsum, int rows, int H, void* stream) {
+  if (!x || !dy || !gamma || !dx || rows <= 0) return PG_ERR_ARG;
+  if (H > LN_STATIC_MAX_H || pg_ln_partial_rows(rows) > LN_STATIC_ROWS) return PG_ERR_SCRATCH;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LN_STATIC_MAX_DEVICES) return PG_ERR_LAUNCH;
+  if (!g_ln_static_ptr[dev]) {
+    float* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(ln_static_scratch)) != hipSuccess || !p) return PG_ERR_LAUNCH;
+    g_ln_static_ptr[dev] = p;
+  }
+  // (every partial row the reduction reads is written by the launch before it: nothing to clear)
+  return ln_bwd_launch<false>(dtype, x, nullptr, dy, nullptr, gamma, eps, dx, dgamma, dbeta, dxsum, g_ln_static_ptr[dev],
+                              rows, H, (hipStream_t)stream);
+}
+
 extern "C" int pg_layernorm_bwd2(int dtype, const void* x, const void* xdot, const void* gy, const void* ybar,
                                  const float* gamma, float eps, void* xbar, float* dgamma, float* dbeta, float* dxsum,
                                  float* partial, int rows, int H, void* stream) {
