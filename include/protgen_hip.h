@@ -99,6 +99,14 @@ typedef struct {
    * the layout and leading dimensions of A / B with reduction extent K2 (0 = none).  The gradient
    * penalty's second-order pass sums two products into each weight gradient. */
   const void* A2; const void* B2; int K2;
+  /* Optional ragged batches (bf16, N <= 64, B stored [K][N]; the key-side contractions of attention over
+   * sequences of different lengths laid back to back): batch (zo, zi) = (sequence, head); device int32
+   * seq_off[batch / batch_inner + 1].  Operands named in seq_ops (1 = A, 2 = B, 4 = C) are token-row
+   * buffers: sequence zo starts at row seq_off[zo] - seq_tok0 (the outer batch stride is ignored) and
+   * M = K = seq_off[zo+1] - seq_off[zo] (the descriptor's M = K bound them and size the grid).  The other
+   * operands are score-shaped slots addressed by the batch strides; whole 64-row tiles of them are read, so
+   * the rows / columns between a sequence's extent and the next multiple of 64 must hold zeros. */
+  const int32_t* seq_off; int seq_tok0; int seq_ops;
 } pg_gemm_desc;
 int pg_gemm(const pg_gemm_desc* d, void* stream);
 /* Two unbatched products in one launch (results identical to pg_gemm(d0) then pg_gemm(d1)):
@@ -136,6 +144,10 @@ int pg_embed_ln2(int dtype, const int64_t* ids, const float* word, const float* 
 int pg_embed_ln_packed(int dtype, const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
                        const float* type0, const float* gamma, const float* beta, float eps, void* out, int T, int H,
                        void* stream);
+/* pg_embed_ln_packed that also stores the pre-LayerNorm sum (for the embedding backward). */
+int pg_embed_ln2_packed(int dtype, const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
+                        const float* type0, const float* gamma, const float* beta, float eps, void* out, void* sum_out,
+                        int T, int H, void* stream);
 /* y = LayerNorm(x) (modeling_bert.py:289-293,347-351; residual is added by the GEMM epilogue). */
 int pg_layernorm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
                  int rows, int H, void* stream);
@@ -208,6 +220,26 @@ int pg_attention_bwd2(int dtype, const void* qkv, const void* tqkv, const void* 
                       const void* gctx, const void* ctxbar, const float* rho, void* Sbar, void* Pdot, int B, int S, int heads,
                       int64_t ld_qkv, int64_t ld_ctx, void* stream);
 
+/* The four training kernels over sequences of different lengths laid back to back ("ragged"): sequence b is
+ * the token rows [seq_off[b] - tok0, seq_off[b+1] - tok0) of every [T][ld] operand (device int32
+ * seq_off[nseq+1]; lengths are multiples of 8, at most max_len).  Score-shaped operands (P, dS, Sbar, Pdot)
+ * hold one slot of ld x ld elements per (sequence, head), ld = pg_score_ld(max_len), of which the leading
+ * len rows and columns are used; outputs carry zeros from there to the next multiple of 64 in both
+ * directions.  rho stays [nseq*heads][max_len].  The reference pads every row to 512 (dataset.py:19-42),
+ * lengths are 200-500: the rows and keys skipped here are the ones its attention mask hides. */
+int pg_attention_fwd_p_ragged(int dtype, const void* qkv, const float* mask, void* P, void* ctx, const int32_t* seq_off,
+                              int nseq, int max_len, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream);
+int pg_attention_bwd_dq_ragged(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
+                               void* dq, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads,
+                               int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream);
+int pg_attention_jvp_ragged(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot,
+                            float* rho, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads, int64_t ld_qkv,
+                            int64_t ld_ctx, int64_t ld_out, void* stream);
+int pg_attention_bwd2_ragged(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
+                             const void* ctxdot, const void* gctx, const void* ctxbar, const float* rho, void* Sbar,
+                             void* Pdot, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads, int64_t ld_qkv,
+                             int64_t ld_ctx, void* stream);
+
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */
@@ -263,16 +295,36 @@ int pg_gp_norms(int dtype, const void* g, const float* mask, int B, int S, int H
                 void* stream);
 int pg_gp_direction(int dtype, const void* g, const float* mask, const float* norms, int B, int S, int H,
                     const float* scale_dev, void* v, float* gp_out, void* stream);
+/* The same two reductions when sample b is the token rows [seq_off[b], seq_off[b+1]) of g / mask / v (every
+ * sample packed to its own length: rows past it have mask 0 in loss.py:87-88 and add nothing). */
+int pg_gp_norms_ragged(int dtype, const void* g, const float* mask, const int32_t* seq_off, int B, int max_len, int H,
+                       float* norms, float* gp_out, void* stream);
+int pg_gp_direction_ragged(int dtype, const void* g, const float* mask, const float* norms, const int32_t* seq_off, int B,
+                           int max_len, int H, const float* scale_dev, void* v, float* gp_out, void* stream);
 /* x = alpha_b * er + (1-alpha_b) * ef (loss.py:29); alpha fp32 [B]. */
 int pg_interpolate(int dtype, const void* er, const void* ef, const float* alpha, void* x, int B, int64_t per_sample,
                    void* stream);
 /* der = alpha_b * dx ; def = (1-alpha_b) * dx */
 int pg_interpolate_bwd(int dtype, const void* dx, const float* alpha, void* der, void* def, int B,
                        int64_t per_sample, void* stream);
+/* loss.py:29 over packed rows: token row t of x is row t - off_x[b] of sequence b = seq_id[t]; the real and fake
+ * embeddings of that sequence start at rows off_r[b], off_f[b] of er, ef (each batch packed to its own
+ * lengths, none shorter than the interpolate's).  All index arrays are device int32.  The backward writes
+ * (accumulate = 0) or adds (1) alpha_b dx and (1 - alpha_b) dx into the same rows of der, def and touches no
+ * other row. */
+int pg_interpolate_ragged(int dtype, const void* er, const void* ef, const float* alpha, void* x, const int32_t* seq_id,
+                          const int32_t* off_x, const int32_t* off_r, const int32_t* off_f, int T, int H, void* stream);
+int pg_interpolate_bwd_ragged(int dtype, const void* dx, const float* alpha, void* der, void* def, const int32_t* seq_id,
+                              const int32_t* off_x, const int32_t* off_r, const int32_t* off_f, int T, int H, int accumulate,
+                              void* stream);
 /* Embedding backward: LayerNorm backward of BertEmbeddings followed by scatter-add into the
  * word / position / token-type tables (fp32 atomics).                                    */
 int pg_embed_scatter(int dtype, const void* dsum, const int64_t* ids, float* gword, float* gpos, float* gtype0, int B,
                      int S, int H, void* stream);
+
+/* The same for T packed token rows with explicit positions (device int32 pos_ids[T]). */
+int pg_embed_scatter_packed(int dtype, const void* dsum, const int64_t* ids, const int32_t* pos_ids, float* gword,
+                            float* gpos, float* gtype0, int T, int H, void* stream);
 
 /* ------------------------------------------------------------------ K12: optimizer
  * torch.optim.AdamW semantics (fully_masked_train.py:74-75,326): decoupled weight decay,
@@ -291,6 +343,29 @@ int pg_scale_f32(float* p, float s, int64_t n, void* stream);
 int64_t pg_workspace_bytes(const pg_model_cfg* cfg, int dtype, int B, int S);
 int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int S);
 
+/* Ragged form of the training passes: the B sequences of a pass have their own lengths (multiples of 8, from 8
+ * to max_len) and lie back to back in T token rows; every token-wise kernel runs on T rows and attention walks
+ * each sequence's own keys.  The critic of the reference sees rows padded to 512 (dataset.py:19-42) whose
+ * attention mask hides the padding (models.py:87-102, loss.py:41-66): hidden columns are never read by a visible
+ * row, the critic reads the first row only (models.py:104), and their gradients are exactly zero, so a pass over
+ * each row's leading columns up to its last visible one gives the same scores and gradients.  `mask` (per token,
+ * T floats) still applies inside a sequence.
+ *   seq_off / seq_off_host: device and host copies of int32 [B+1]; seq_off[b] = token row of sequence b in the
+ *     buffers of the forward that wrote the primal stash (so a pass over a sub-range of that forward's sequences
+ *     passes a pointer into the same array), seq_off[B] = end of the last one.
+ *   stash_T: token rows of that forward (0 = this pass covers all of them).
+ *   adj_T (pg_encoder_backward2): token rows of the pass that wrote the adjoint stash (0 = same as this pass).
+ * Workspace and stash sizes: the *_ragged functions below (T token rows, score slots for B x max_len). */
+typedef struct {
+  int max_len;
+  const int32_t* seq_off;
+  const int32_t* seq_off_host;
+  int stash_T;
+  int adj_T;
+} pg_ragged;
+int64_t pg_workspace_bytes_ragged(const pg_model_cfg* cfg, int dtype, int B, int max_len, int T);
+int64_t pg_stash_bytes_ragged(const pg_model_cfg* cfg, int dtype, int B, int max_len, int T);
+
 /* Forward through embeddings (if ids != NULL, else x_in [B,S,H] is the encoder input, as in
  * models.py:94-102 / loss.py:62-66) and all encoder layers.  mask: float [B,S] or NULL.
  * hidden_out [B,S,H] activation dtype.  stash may be NULL (inference).  emb_sum_out
@@ -307,6 +382,14 @@ int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, int dtype, i
 int pg_encoder_forward_packed(const pg_model_cfg* cfg, const pg_params* p, int dtype, int nseq, int max_len,
                               const int32_t* seq_off, int T, const int64_t* ids, const int32_t* pos_ids, const float* mask,
                               void* workspace, int64_t workspace_bytes, void* hidden_out, void* stream);
+/* pg_encoder_forward over ragged sequences, with every option of the rectangular form: ids + pos_ids (device
+ * int64 / int32 [T]) or x_in [T,H]; mask float [T] or NULL; stash for a backward (pg_stash_bytes_ragged);
+ * hidden_out [T,H]; emb_sum_out [T,H] (ids path).  fp32 runs the attention of each sequence as its own launches
+ * (seq_off_host), bf16 the fused ragged kernels. */
+int pg_encoder_forward_ragged(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, const pg_ragged* rg,
+                              const int64_t* ids, const int32_t* pos_ids, const void* x_in, const float* mask,
+                              void* workspace, int64_t workspace_bytes, void* stash, void* hidden_out, void* emb_sum_out,
+                              void* stream);
 /* MLM head up to logits (Generator.forward, models.py:14-16): fp32 logits [T][V]. */
 int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T, void* workspace,
                   int64_t workspace_bytes, float* logits, void* stream);
@@ -328,24 +411,26 @@ int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const 
  * grad_row0 (pg_encoder_backward): parameter gradients are accumulated from the sequences grad_row0.. only;
  * the sequences before them get their input gradient and adjoints (the interpolates of the gradient penalty
  * in one backward with the real and fake rows).  adj_rows (pg_encoder_backward2; 0 = B): the adjoint stash was
- * written by such a pass over adj_rows sequences, this pass's B sequences are its first.    */
+ * written by such a pass over adj_rows sequences, this pass's B sequences are its first.
+ * rg (last argument of the three passes; NULL = B x S rectangle): the pass is ragged, S = rg->max_len, and
+ * d_hidden / dx_out / xdot_in / hdot_out / xbar_out hold this pass's T = seq_off[B] - seq_off[0] token rows.  */
 #define PG_BWD_PARAM_GRADS 1
 #define PG_BWD_SAVE_ADJOINTS 2
 int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                         void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                        int stash_rows, int stash_row0, int grad_row0);
+                        int stash_rows, int stash_row0, int grad_row0, const pg_ragged* rg);
 /* GP tangent-forward pass: xdot_in [B,S,H] -> hdot_out [B,S,H]; writes the tangent stash. */
 int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                    const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
-                   void* stream, int stash_rows, int stash_row0);
+                   void* stream, int stash_rows, int stash_row0, const pg_ragged* rg);
 /* GP second-order reverse over (primal stash, adjoint stash, tangent stash): accumulates
  * d<v, ds/dx>/dtheta into p->grad (flags bit0; any loss weight is folded into v by
  * pg_gp_direction) and writes the gradient w.r.t. the encoder input x to xbar_out (nullable). */
 int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                          const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
                          void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                         int stash_rows, int stash_row0, int adj_rows);
+                         int stash_rows, int stash_row0, int adj_rows, const pg_ragged* rg);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,13 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_float),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("aux", C.c_void_p), ("ldaux", C.c_int64), ("aux2", C.c_void_p), ("act", C.c_int),
-                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int)]
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int),
+                ("seq_off", C.c_void_p), ("seq_tok0", C.c_int), ("seq_ops", C.c_int)]
+
+
+class RaggedDesc(C.Structure):
+    _fields_ = [("max_len", C.c_int), ("seq_off", C.c_void_p), ("seq_off_host", C.c_void_p), ("stash_T", C.c_int),
+                ("adj_T", C.c_int)]
 
 
 if not os.path.exists(LIB_PATH):
@@ -50,6 +56,7 @@ lib = C.CDLL(LIB_PATH)
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 cfgp = C.POINTER(ModelCfg)
 parp = C.POINTER(Params)
+ragp = C.POINTER(RaggedDesc)
 
 SIGNATURES = {
     "pg_strerror": (C.c_char_p, [i32]),
@@ -107,12 +114,25 @@ SIGNATURES = {
     "pg_stash_bytes": (i64, [cfgp, i32, i32, i32]),
     "pg_encoder_forward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "pg_mlm_logits": (i32, [cfgp, parp, i32, vp, i32, vp, i64, vp, vp]),
-    "pg_encoder_backward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i32, i32, i32]),
+    "pg_encoder_backward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i32, i32, i32, ragp]),
+    "pg_encoder_forward_ragged": (i32, [cfgp, parp, i32, i32, ragp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "pg_workspace_bytes_ragged": (i64, [cfgp, i32, i32, i32, i32]),
+    "pg_stash_bytes_ragged": (i64, [cfgp, i32, i32, i32, i32]),
+    "pg_attention_fwd_p_ragged": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp]),
+    "pg_attention_bwd_dq_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "pg_attention_jvp_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "pg_attention_bwd2_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp]),
+    "pg_embed_ln2_packed": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]),
+    "pg_embed_scatter_packed": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "pg_gp_norms_ragged": (i32, [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "pg_gp_direction_ragged": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "pg_interpolate_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "pg_interpolate_bwd_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "pg_encoder_forward_packed": (i32, [cfgp, parp, i32, i32, i32, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
     "pg_embed_ln_packed": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp]),
     "pg_attention_fwd_packed": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i64, i64, vp]),
-    "pg_encoder_jvp": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, i32, i32]),
-    "pg_encoder_backward2": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp, vp, i32, i32, i32]),
+    "pg_encoder_jvp": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, i32, i32, ragp]),
+    "pg_encoder_backward2": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp, vp, i32, i32, i32, ragp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

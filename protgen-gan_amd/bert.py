@@ -526,15 +526,58 @@ class ProtBertForMaskedLM(nn.Module):
         check(lib.pg_embed_scatter(dt, dsum.data_ptr(), ids.data_ptr(), self._gg(_lib.P_WORD_EMB), self._gg(_lib.P_POS_EMB),
                                    self._gg(_lib.P_TYPE_EMB), B, S, H, ops.stream()), "pg_embed_scatter")
 
-    def _ws(self, B, S):
-        n = lib.pg_workspace_bytes(C.byref(self._ccfg), ops.dt_code(self.compute_dtype), B, S)
+    def _ws(self, B, S, T=None):
+        """Workspace for a pass over B x S, or (T given) over T ragged token rows of B sequences of at most S."""
+        dt = ops.dt_code(self.compute_dtype)
+        n = (lib.pg_workspace_bytes(C.byref(self._ccfg), dt, B, S) if T is None
+             else lib.pg_workspace_bytes_ragged(C.byref(self._ccfg), dt, B, S, T))
         if n < 0:
             raise ValueError("unsupported shape")
         return workspace(self.device, n), n
 
-    def _new_stash(self, B, S):
-        n = lib.pg_stash_bytes(C.byref(self._ccfg), ops.dt_code(self.compute_dtype), B, S)
+    def _new_stash(self, B, S, T=None):
+        dt = ops.dt_code(self.compute_dtype)
+        n = (lib.pg_stash_bytes(C.byref(self._ccfg), dt, B, S) if T is None
+             else lib.pg_stash_bytes_ragged(C.byref(self._ccfg), dt, B, S, T))
         return torch.empty(n, dtype=torch.uint8, device=self.device)
+
+    # -- ragged passes (rows of different lengths laid back to back; see ragged.py)
+    def _embed_packed(self, ids_p, pos_p, out, esum):
+        """Embeddings + LayerNorm of T packed tokens (int64 ids, int32 positions) into out [T,H] (and the
+        pre-LayerNorm sum into esum, when given)."""
+        T = ids_p.numel()
+        check(lib.pg_embed_ln2_packed(ops.dt_code(self.compute_dtype), ids_p.data_ptr(), pos_p.data_ptr(),
+                                      self._gp(_lib.P_WORD_EMB), self._gp(_lib.P_POS_EMB), self._gp(_lib.P_TYPE_EMB),
+                                      self._gp(_lib.P_EMB_LN_G), self._gp(_lib.P_EMB_LN_B), self.config.layer_norm_eps,
+                                      out.data_ptr(), ops.ptr(esum), T, self.config.hidden_size, ops.stream()),
+              "pg_embed_ln2_packed")
+
+    def _embed_backward_packed(self, ids_p, pos_p, esum, dout):
+        T = ids_p.numel()
+        H = self.config.hidden_size
+        dt = ops.dt_code(self.compute_dtype)
+        dsum = torch.empty_like(esum)
+        part = torch.empty(3 * H * lib.pg_ln_partial_rows(T), dtype=torch.float32, device=ids_p.device)
+        check(lib.pg_layernorm_bwd(dt, esum.data_ptr(), dout.data_ptr(), self._gp(_lib.P_EMB_LN_G),
+                                   self.config.layer_norm_eps, dsum.data_ptr(), self._gg(_lib.P_EMB_LN_G),
+                                   self._gg(_lib.P_EMB_LN_B), None, part.data_ptr(), T, H, ops.stream()), "pg_layernorm_bwd")
+        check(lib.pg_embed_scatter_packed(dt, dsum.data_ptr(), ids_p.data_ptr(), pos_p.data_ptr(), self._gg(_lib.P_WORD_EMB),
+                                          self._gg(_lib.P_POS_EMB), self._gg(_lib.P_TYPE_EMB), T, H, ops.stream()),
+              "pg_embed_scatter_packed")
+
+    def _encode_ragged(self, rg, ids_p=None, pos_p=None, x=None, mask_p=None, want_stash=False, esum=None):
+        """Forward over the ragged batch `rg` (a ragged.Ragged): packed ids + positions, or x [T,H]; mask_p fp32 [T]
+        or None.  Returns (hidden [T,H], stash or None)."""
+        dt = ops.dt_code(self.compute_dtype)
+        ws, n = self._ws(rg.B, rg.S, rg.T)
+        stash = self._new_stash(rg.B, rg.S, rg.T) if want_stash else None
+        hidden = torch.empty(rg.T, self.config.hidden_size, dtype=self.compute_dtype, device=self.device)
+        pr = _params_struct(self.store, self.compute_dtype, False)
+        d = rg.desc()
+        check(lib.pg_encoder_forward_ragged(C.byref(self._ccfg), C.byref(pr), dt, rg.B, C.byref(d), ops.ptr(ids_p), ops.ptr(pos_p),
+                                            ops.ptr(x), ops.ptr(mask_p), ws.data_ptr(), n, ops.ptr(stash), hidden.data_ptr(),
+                                            ops.ptr(esum), ops.stream()), "pg_encoder_forward_ragged")
+        return hidden, stash
 
     def _encode(self, ids, x, mask, want_stash=False, esum=None):
         """Embeddings (if ids) + all encoder layers.  Returns (hidden [B,S,H], stash or None)."""
@@ -564,36 +607,42 @@ class ProtBertForMaskedLM(nn.Module):
                                             hidden.data_ptr(), ops.stream()), "pg_encoder_forward_packed")
         return hidden
 
-    def _encode_backward(self, stash, dh, B, S, param_grads, adj_stash=None, stash_rows=0, row0=0, grad_row0=0):
+    # `rgd` below: a _lib.RaggedDesc (ragged.Ragged.desc(...)) when the pass is ragged, with `T` its token rows.
+    def _encode_backward(self, stash, dh, B, S, param_grads, adj_stash=None, stash_rows=0, row0=0, grad_row0=0, rgd=None, T=None):
         dt = ops.dt_code(self.compute_dtype)
-        ws, n = self._ws(B, S)
+        ws, n = self._ws(B, S, T if rgd is not None else None)
         flags = (PG_BWD_PARAM_GRADS if param_grads else 0) | (PG_BWD_SAVE_ADJOINTS if adj_stash is not None else 0)
         dx = torch.empty_like(dh)
         pr = _params_struct(self.store, self.compute_dtype, param_grads)
         check(lib.pg_encoder_backward(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), dh.data_ptr(), None,
                                       flags, ops.ptr(adj_stash), dx.data_ptr(), ws.data_ptr(), n, ops.stream(),
-                                      self._layer_event_arr if param_grads else None, stash_rows, row0, grad_row0),
+                                      self._layer_event_arr if param_grads else None, stash_rows, row0, grad_row0,
+                                      C.byref(rgd) if rgd is not None else None),
               "pg_encoder_backward")
         return dx
 
-    def _encode_jvp(self, stash, xdot, B, S, tan_stash, stash_rows=0, row0=0):
+    def _encode_jvp(self, stash, xdot, B, S, tan_stash, stash_rows=0, row0=0, rgd=None, T=None):
         dt = ops.dt_code(self.compute_dtype)
-        ws, n = self._ws(B, S)
+        ws, n = self._ws(B, S, T if rgd is not None else None)
         hdot = torch.empty_like(xdot)
         pr = _params_struct(self.store, self.compute_dtype, False)
         check(lib.pg_encoder_jvp(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), xdot.data_ptr(),
-                                 tan_stash.data_ptr(), hdot.data_ptr(), ws.data_ptr(), n, ops.stream(), stash_rows, row0),
+                                 tan_stash.data_ptr(), hdot.data_ptr(), ws.data_ptr(), n, ops.stream(), stash_rows, row0,
+                                 C.byref(rgd) if rgd is not None else None),
               "pg_encoder_jvp")
         return hdot
 
-    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0, adj_rows=0):
+    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0, adj_rows=0, rgd=None, T=None):
         dt = ops.dt_code(self.compute_dtype)
-        ws, n = self._ws(B, S)
-        xbar = torch.empty(B, S, self.config.hidden_size, dtype=self.compute_dtype, device=self.device) if want_xbar else None
+        ws, n = self._ws(B, S, T if rgd is not None else None)
+        H = self.config.hidden_size
+        shape = (T, H) if rgd is not None else (B, S, H)
+        xbar = torch.empty(*shape, dtype=self.compute_dtype, device=self.device) if want_xbar else None
         pr = _params_struct(self.store, self.compute_dtype, True)
         check(lib.pg_encoder_backward2(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), adj.data_ptr(),
                                        tan.data_ptr(), PG_BWD_PARAM_GRADS, ops.ptr(xbar), ws.data_ptr(), n, ops.stream(),
-                                       self._layer_event_arr, stash_rows, row0, adj_rows),
+                                       self._layer_event_arr, stash_rows, row0, adj_rows,
+                                       C.byref(rgd) if rgd is not None else None),
               "pg_encoder_backward2")
         return xbar
 

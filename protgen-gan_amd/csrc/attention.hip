@@ -42,6 +42,31 @@ __device__ __forceinline__ u32x2 rdtr(unsigned addr) {
   return v;
 }
 
+// Sequences of different lengths laid back to back ("ragged"): sequence b of a launch is the token rows
+// [seq_off[b] - tok0, seq_off[b+1] - tok0) of every [T][ld] activation operand; score-shaped operands keep
+// one slot of slot_rows x ldS per (sequence, head), of which the leading len rows / columns are used.  A
+// kernel that writes score-shaped output also writes zeros into the rows [len, 64-multiple): the key-side
+// contractions over these buffers reduce over whole 64-row tiles.  seq_off == NULL: B x S rectangle.
+struct RaggedArgs { const int* seq_off; int tok0; int slot_rows; };
+struct SeqSpan { long row0; int len, store_rows, slot_rows; };
+__device__ __forceinline__ SeqSpan seq_span(const RaggedArgs& rg, int b, int S) {
+  SeqSpan sp;
+  if (rg.seq_off) {
+    const int a = rg.seq_off[b];
+    sp.row0 = a - rg.tok0;
+    sp.len = rg.seq_off[b + 1] - a;
+    const int pad = (sp.len + 63) & ~63;
+    sp.store_rows = pad < rg.slot_rows ? pad : rg.slot_rows;
+    sp.slot_rows = rg.slot_rows;
+  } else {
+    sp.row0 = (long)b * S;
+    sp.len = S;
+    sp.store_rows = S;
+    sp.slot_rows = S;
+  }
+  return sp;
+}
+
 // One 64-row x 128-byte tile: 8 wave-instructions of 1 KiB, two per wave.
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long ld, int row0, int rows_max, bf16_t* lds_tile,
                                            int wid, int lane) {
@@ -269,19 +294,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 // That replaces an fp32 score matrix round trip (GEMM store, softmax load/store, GEMM load).
 __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
                                                              bf16_t* __restrict__ P, bf16_t* __restrict__ ctx, int S, int ldS,
-                                                             int heads, long ld_qkv, long ld_ctx) {
+                                                             int heads, long ld_qkv, long ld_ctx, RaggedArgs rg) {
   __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;
   const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * QB >= sp.store_rows) return;
+  S = sp.len;
+  const long row0 = sp.row0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int H = heads * 64;
-  const bf16_t* Q = qkv + (long)b * S * ld_qkv + h * 64;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
   const bf16_t* K = Q + H;
   const bf16_t* V = Q + 2 * H;
-  const float* mrow = mask ? mask + (long)b * S : nullptr;
+  const float* mrow = mask ? mask + row0 : nullptr;
   const int q0 = qt * QB + wid * 32;
 
   bf16x8_t qf[2][2];
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
   stage_tile(K, ld_qkv, 0, S, smem, wid, lane);
   stage_tile(V, ld_qkv, 0, S, smem + TILE, wid, lane);
   __syncthreads();
-  bf16_t* Pz = P + (long)bh * S * ldS;
+  bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) {
       bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
@@ -426,10 +455,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
         float pv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          pv[e] = __expf(s[qg][blk][e] - m_run[qg]) * inv_l[qg];
+          pv[e] = q < S ? __expf(s[qg][blk][e] - m_run[qg]) * inv_l[qg] : 0.f;  // (rows past the sequence: zeros)
           s[qg][blk][e] = pv[e];
         }
-        if (q < S) VecIO<bf16_t, 4>::store(Pz + (long)q * ldS + t * KT + blk * 16 + 4 * g, pv);
+        if (q < sp.store_rows) VecIO<bf16_t, 4>::store(Pz + (long)q * ldS + t * KT + blk * 16 + 4 * g, pv);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -459,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
   for (int qg = 0; qg < 2; ++qg) {
     const int q = q0 + qg * 16 + r;
     if (q >= S) continue;
-    bf16_t* dst = ctx + ((long)b * S + q) * ld_ctx + h * 64 + 4 * g;
+    bf16_t* dst = ctx + (row0 + q) * ld_ctx + h * 64 + 4 * g;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       float v[4] = {o[qg][d][0], o[qg][d][1], o[qg][d][2], o[qg][d][3]};
@@ -477,16 +506,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
                                                               const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ dq, int S, int ldS,
-                                                              int heads, long ld_qkv, long ld_ctx, long ld_dq) {
+                                                              int heads, long ld_qkv, long ld_ctx, long ld_dq, RaggedArgs rg) {
   __shared__ __align__(16) bf16_t smem[4 * TILE];
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;
   const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * QB >= sp.store_rows) return;
+  S = sp.len;
+  const long row0 = sp.row0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int H = heads * 64;
-  const bf16_t* K = qkv + (long)b * S * ld_qkv + h * 64 + H;
+  const bf16_t* K = qkv + row0 * ld_qkv + h * 64 + H;
   const bf16_t* V = K + H;
   const int q0 = qt * QB + wid * 32;
 
@@ -502,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     float acc = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const long o = ((long)b * S + q) * ld_ctx + h * 64 + kk * 32 + 8 * g;
+      const long o = (row0 + q) * ld_ctx + h * 64 + kk * 32 + 8 * g;
       uint4 dv = *reinterpret_cast<const uint4*>(dctx + o);
       uint4 ov = *reinterpret_cast<const uint4*>(ctx + o);
       df[qg][kk] = __builtin_bit_cast(bf16x8_t, dv);
@@ -533,8 +566,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
-  const bf16_t* Pz = P + (long)bh * S * ldS;
-  bf16_t* dSz = dS + (long)bh * S * ldS;
+  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
+  bf16_t* dSz = dS + (long)bh * sp.slot_rows * ldS;
 
   f32x4 o[2][4];
 #pragma unroll
@@ -607,8 +640,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         float ds[4] = {p0 * (dp[qg][blk][0] - delta[qg]), p1 * (dp[qg][blk][1] - delta[qg]),
                        p2 * (dp[qg][blk][2] - delta[qg]), p3 * (dp[qg][blk][3] - delta[qg])};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dp[qg][blk][e] = ds[e];
-        if (q < S) VecIO<bf16_t, 4>::store(dSz + (long)q * ldS + t * KT + blk * 16 + 4 * g, ds);
+        for (int e = 0; e < 4; ++e) {
+          if (q >= S) ds[e] = 0.f;  // (rows past the sequence: zeros)
+          dp[qg][blk][e] = ds[e];
+        }
+        if (q < sp.store_rows) VecIO<bf16_t, 4>::store(dSz + (long)q * ldS + t * KT + blk * 16 + 4 * g, ds);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -642,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   for (int qg = 0; qg < 2; ++qg) {
     const int q = q0 + qg * 16 + r;
     if (q >= S) continue;
-    bf16_t* dst = dq + ((long)b * S + q) * ld_dq + h * 64 + 4 * g;
+    bf16_t* dst = dq + (row0 + q) * ld_dq + h * 64 + 4 * g;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       float v[4] = {o[qg][d][0] * 0.125f, o[qg][d][1] * 0.125f, o[qg][d][2] * 0.125f, o[qg][d][3] * 0.125f};
@@ -727,16 +763,20 @@ __device__ __forceinline__ void score_product1(const u32x4 (&tf)[4][2], const bf
 __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ tqkv,
                                                            const bf16_t* __restrict__ P, const bf16_t* __restrict__ ctx,
                                                            bf16_t* __restrict__ ctxdot, float* __restrict__ rho, int S, int ldS,
-                                                           int heads, long ld_qkv, long ld_ctx, long ld_out) {
+                                                           int heads, long ld_qkv, long ld_ctx, long ld_out, RaggedArgs rg) {
   __shared__ __align__(16) bf16_t smem[8 * TILE];  // [buffer][K | dK | V | dV]
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;
   const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * QB >= sp.len) return;
+  const int rho_stride = S;  // rho stays [B*heads][S of the launch]
+  S = sp.len;
+  const long row0 = sp.row0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int H = heads * 64;
-  const long row0 = (long)b * S;
   const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
   const bf16_t* Qd = tqkv + row0 * ld_qkv + h * 64;
   const int q0 = qt * QB + wid * 32;
@@ -767,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
   }
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
-  const bf16_t* Pz = P + (long)bh * S * ldS;
+  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
 
   f32x4 o[2][4];
   float racc[2] = {0.f, 0.f};
@@ -899,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
     rq += __shfl_xor(rq, 32, 64);
     const int q = q0 + qg * 16 + r;
     if (q >= S) continue;
-    if (g == 0) rho[(long)bh * S + q] = rq;
+    if (g == 0) rho[(long)bh * rho_stride + q] = rq;
     const bf16_t* cs = ctx + (row0 + q) * ld_ctx + h * 64 + 4 * g;
     bf16_t* dst = ctxdot + (row0 + q) * ld_out + h * 64 + 4 * g;
 #pragma unroll
@@ -922,16 +962,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
                                                             const bf16_t* __restrict__ ctxdot, const bf16_t* __restrict__ gctx,
                                                             const bf16_t* __restrict__ ctxbar, const float* __restrict__ rho,
                                                             bf16_t* __restrict__ Sbar, bf16_t* __restrict__ Pdot, int S, int ldS,
-                                                            int heads, long ld_qkv, long ld_ctx) {
+                                                            int heads, long ld_qkv, long ld_ctx, RaggedArgs rg) {
   __shared__ __align__(16) bf16_t smem[8 * TILE];  // [buffer][K | dK | V | dV]
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;
   const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * QB >= sp.store_rows) return;
+  const int rho_stride = S;
+  S = sp.len;
+  const long row0 = sp.row0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int H = heads * 64;
-  const long row0 = (long)b * S;
   const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
   const bf16_t* Qd = tqkv + row0 * ld_qkv + h * 64;
   const int q0 = qt * QB + wid * 32;
@@ -957,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
     row_dots(gf, cdf, e2);
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
-      rq[qg] = rho[(long)bh * S + qrow[qg]];
+      rq[qg] = rho[(long)bh * rho_stride + qrow[qg]];
       eq[qg] = e1[qg] + e2[qg] - rq[qg] * cq[qg];
     }
   }
@@ -967,9 +1011,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
   for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
-  const bf16_t* Pz = P + (long)bh * S * ldS;
-  bf16_t* Sbz = Sbar + (long)bh * S * ldS;
-  bf16_t* Pdz = Pdot + (long)bh * S * ldS;
+  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
+  bf16_t* Sbz = Sbar + (long)bh * sp.slot_rows * ldS;
+  bf16_t* Pdz = Pdot + (long)bh * sp.slot_rows * ldS;
 
   uint2 pcur[2][4], pnext[2][4];
 #pragma unroll
@@ -1036,10 +1080,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
         for (int e = 0; e < 4; ++e) {
           const float d = ds[blk][e] * 0.125f;
           const float pbar = xx[blk][e] + gm[blk][e] * (d - rq[qg]) - cq[qg] * d;
-          sb[e] = pv[e] * (pbar - eq[qg]);
-          pd[e] = pv[e] * (d - rq[qg]);
+          sb[e] = q < S ? pv[e] * (pbar - eq[qg]) : 0.f;  // (rows past the sequence: zeros)
+          pd[e] = q < S ? pv[e] * (d - rq[qg]) : 0.f;
         }
-        if (q < S) {
+        if (q < sp.store_rows) {
           const long o = (long)q * ldS + t * KT + blk * 16 + 4 * g;
           VecIO<bf16_t, 4>::store(Sbz + o, sb);
           VecIO<bf16_t, 4>::store(Pdz + o, pd);
@@ -1079,60 +1123,123 @@ extern "C" int pg_attention_fwd_packed(int dtype, const void* qkv, const float* 
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-extern "C" int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
-                                  int64_t ld_qkv, int64_t ld_ctx, void* stream) {
-  if (!qkv || !ctx || !P || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+namespace {
+struct RaggedHost { RaggedArgs rg; int S, ldS; dim3 grid; };
+// Rectangular launch (seq_off == NULL: B sequences of S) or ragged launch (nseq sequences of at most max_len).
+inline RaggedHost ragged_host(const int32_t* seq_off, int n, int S, int tok0, int heads) {
+  RaggedHost h;
+  h.S = S;
+  h.ldS = pg_score_ld(S);
+  h.rg = RaggedArgs{seq_off, tok0, seq_off ? h.ldS : S};
+  h.grid = dim3(((seq_off ? h.ldS : S) + QB - 1) / QB, n * heads);
+  return h;
+}
+
+int launch_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, const int32_t* seq_off, int n, int S,
+                 int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!qkv || !ctx || !P || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)P) & 7)) return PG_ERR_ALIGN;
-  dim3 grid((S + QB - 1) / QB, B * heads);
-  hipLaunchKernelGGL(attn_fwd_p_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
-                     (bf16_t*)ctx, S, pg_score_ld(S), heads, (long)ld_qkv, (long)ld_ctx);
+  const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  hipLaunchKernelGGL(attn_fwd_p_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
+                     (bf16_t*)ctx, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-extern "C" int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
-                                   void* dq, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
-                                   void* stream) {
-  if (!qkv || !P || !ctx || !dctx || !dS || !dq || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+int launch_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dq,
+                  const int32_t* seq_off, int n, int S, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
+                  void* stream) {
+  if (!qkv || !P || !ctx || !dctx || !dS || !dq || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 8) || (ld_dq % 4)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)ctx) | ((uintptr_t)dctx)) & 15) return PG_ERR_ALIGN;
   if ((((uintptr_t)P) | ((uintptr_t)dS) | ((uintptr_t)dq)) & 7) return PG_ERR_ALIGN;
-  dim3 grid((S + QB - 1) / QB, B * heads);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
-                     (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, pg_score_ld(S), heads, (long)ld_qkv,
-                     (long)ld_ctx, (long)ld_dq);
+  const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                     (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
+                     (long)ld_ctx, (long)ld_dq, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-extern "C" int pg_attention_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot,
-                                float* rho, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out,
-                                void* stream) {
-  if (!qkv || !tqkv || !P || !ctx || !ctxdot || !rho || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+int launch_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot, float* rho,
+               const int32_t* seq_off, int n, int S, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out,
+               void* stream) {
+  if (!qkv || !tqkv || !P || !ctx || !ctxdot || !rho || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 4) || (ld_out % 4)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)tqkv)) & 15) return PG_ERR_ALIGN;
   if ((((uintptr_t)P) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot)) & 7) return PG_ERR_ALIGN;
-  dim3 grid((S + QB - 1) / QB, B * heads);
-  hipLaunchKernelGGL(attn_jvp_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
-                     (const bf16_t*)P, (const bf16_t*)ctx, (bf16_t*)ctxdot, rho, S, pg_score_ld(S), heads, (long)ld_qkv,
-                     (long)ld_ctx, (long)ld_out);
+  const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  hipLaunchKernelGGL(attn_jvp_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
+                     (const bf16_t*)P, (const bf16_t*)ctx, (bf16_t*)ctxdot, rho, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx,
+                     (long)ld_out, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-extern "C" int pg_attention_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
-                                 const void* ctxdot, const void* gctx, const void* ctxbar, const float* rho, void* Sbar,
-                                 void* Pdot, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+int launch_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, const void* ctxdot,
+                const void* gctx, const void* ctxbar, const float* rho, void* Sbar, void* Pdot, const int32_t* seq_off, int n,
+                int S, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
   if (!qkv || !tqkv || !P || !ctx || !ctxdot || !gctx || !ctxbar || !rho || !Sbar || !Pdot) return PG_ERR_ARG;
-  if (B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+  if (n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 8)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)tqkv) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot) | ((uintptr_t)gctx) | ((uintptr_t)ctxbar)) & 15)
     return PG_ERR_ALIGN;
   if ((((uintptr_t)P) | ((uintptr_t)Sbar) | ((uintptr_t)Pdot)) & 7) return PG_ERR_ALIGN;
-  dim3 grid((S + QB - 1) / QB, B * heads);
-  hipLaunchKernelGGL(attn_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
+  const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  hipLaunchKernelGGL(attn_bwd2_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
                      (const bf16_t*)P, (const bf16_t*)ctx, (const bf16_t*)ctxdot, (const bf16_t*)gctx, (const bf16_t*)ctxbar, rho,
-                     (bf16_t*)Sbar, (bf16_t*)Pdot, S, pg_score_ld(S), heads, (long)ld_qkv, (long)ld_ctx);
+                     (bf16_t*)Sbar, (bf16_t*)Pdot, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int pg_attention_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* ctx, int B, int S, int heads,
+                                  int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  return launch_fwd_p(dtype, qkv, mask, P, ctx, nullptr, B, S, 0, heads, ld_qkv, ld_ctx, stream);
+}
+extern "C" int pg_attention_fwd_p_ragged(int dtype, const void* qkv, const float* mask, void* P, void* ctx,
+                                         const int32_t* seq_off, int nseq, int max_len, int tok0, int heads, int64_t ld_qkv,
+                                         int64_t ld_ctx, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return launch_fwd_p(dtype, qkv, mask, P, ctx, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, stream);
+}
+
+extern "C" int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
+                                   void* dq, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
+                                   void* stream) {
+  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, nullptr, B, S, 0, heads, ld_qkv, ld_ctx, ld_dq, stream);
+}
+extern "C" int pg_attention_bwd_dq_ragged(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx,
+                                          void* dS, void* dq, const int32_t* seq_off, int nseq, int max_len, int tok0,
+                                          int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, ld_dq, stream);
+}
+
+extern "C" int pg_attention_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot,
+                                float* rho, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out,
+                                void* stream) {
+  return launch_jvp(dtype, qkv, tqkv, P, ctx, ctxdot, rho, nullptr, B, S, 0, heads, ld_qkv, ld_ctx, ld_out, stream);
+}
+extern "C" int pg_attention_jvp_ragged(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
+                                       void* ctxdot, float* rho, const int32_t* seq_off, int nseq, int max_len, int tok0,
+                                       int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_out, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return launch_jvp(dtype, qkv, tqkv, P, ctx, ctxdot, rho, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, ld_out, stream);
+}
+
+extern "C" int pg_attention_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
+                                 const void* ctxdot, const void* gctx, const void* ctxbar, const float* rho, void* Sbar,
+                                 void* Pdot, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  return launch_bwd2(dtype, qkv, tqkv, P, ctx, ctxdot, gctx, ctxbar, rho, Sbar, Pdot, nullptr, B, S, 0, heads, ld_qkv, ld_ctx,
+                     stream);
+}
+extern "C" int pg_attention_bwd2_ragged(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx,
+                                        const void* ctxdot, const void* gctx, const void* ctxbar, const float* rho, void* Sbar,
+                                        void* Pdot, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads,
+                                        int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return launch_bwd2(dtype, qkv, tqkv, P, ctx, ctxdot, gctx, ctxbar, rho, Sbar, Pdot, seq_off, nseq, max_len, tok0, heads,
+                     ld_qkv, ld_ctx, stream);
 }

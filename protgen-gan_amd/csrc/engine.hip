@@ -19,8 +19,19 @@ namespace {
 
 struct Dims {
   int B, S, H, I, nh, L, V, ldS;
-  long T, Z;
+  int Srows;  // rows of one score slot: S, or (ragged passes) ldS so that whole 64-row tiles stay inside it
+  long T, Z;  // token rows (B*S, or the packed count of a ragged pass), score slots
   int es;  // activation element size
+};
+
+// Ragged pass: sequence b = token rows [off_h[b] - tok0, off_h[b+1] - tok0) of this pass's buffers.
+struct Rag {
+  const int32_t* off = nullptr;    // device
+  const int32_t* off_h = nullptr;  // host copy
+  int tok0 = 0, B = 0;
+  bool on() const { return off != nullptr; }
+  long row(int b) const { return (long)off_h[b] - tok0; }
+  int len(int b) const { return off_h[b + 1] - off_h[b]; }
 };
 
 inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
@@ -36,7 +47,7 @@ StashLayout stash_layout(const Dims& d) {
   const long th = align_up(d.T * d.H * d.es, 256);
   const long ti = align_up(d.T * d.I * d.es, 256);
   const long t3 = align_up(d.T * 3 * d.H * d.es, 256);
-  const long ss = align_up(d.Z * d.S * d.ldS * d.es, 256);
+  const long ss = align_up(d.Z * d.Srows * d.ldS * d.es, 256);
   s.xs = 0;
   s.layer0 = th * (d.L + 1);
   long o = 0;
@@ -75,11 +86,11 @@ Workspace ws_layout(const Dims& d, char* base) {
   Workspace w;
   long o = 0;
   auto take = [&](long bytes) { char* p = base ? base + o : nullptr; o += align_up(bytes, 256); return p; };
-  const long scb = d.Z * d.S * d.ldS * 4L;
+  const long scb = d.Z * d.Srows * d.ldS * 4L;
   w.sc0 = (float*)take(scb);
   w.sc1 = (float*)take(scb);
-  w.ss0 = take(d.Z * d.S * d.ldS * (long)d.es);
-  w.ss1 = take(d.Z * d.S * d.ldS * (long)d.es);
+  w.ss0 = take(d.Z * d.Srows * d.ldS * (long)d.es);
+  w.ss1 = take(d.Z * d.Srows * d.ldS * (long)d.es);
   w.qkv = take(d.T * 3 * d.H * d.es);
   w.ctx = take(d.T * d.H * d.es);
   w.a = take(d.T * d.H * d.es);
@@ -108,9 +119,44 @@ bool make_dims(const pg_model_cfg* c, int dtype, int B, int S, Dims& d) {
   if (dtype != PG_F32 && dtype != PG_BF16) return false;
   d.B = B; d.S = S; d.H = c->hidden; d.I = c->inter; d.nh = c->heads; d.L = c->layers; d.V = c->vocab_size;
   d.ldS = pg_score_ld(S);
+  d.Srows = S;
   d.T = (long)B * S; d.Z = (long)B * c->heads;
   d.es = dtype == PG_F32 ? 4 : 2;
   return true;
+}
+
+// Dims of a ragged pass (rg != NULL) or of the B x S rectangle.  Lengths must be multiples of 8 in 8..max_len.
+bool make_dims_rg(const pg_model_cfg* c, int dtype, int B, int S, const pg_ragged* rg, Dims& d, Rag& r) {
+  r = Rag();
+  if (!rg) return make_dims(c, dtype, B, S, d);
+  if (!rg->seq_off || !rg->seq_off_host || rg->max_len != S || (S % 8)) return false;
+  if (!make_dims(c, dtype, B, S, d)) return false;
+  r.off = rg->seq_off; r.off_h = rg->seq_off_host; r.tok0 = rg->seq_off_host[0]; r.B = B;
+  if (r.tok0 < 0) return false;
+  for (int b = 0; b < B; ++b) {
+    const int len = r.len(b);
+    if (len < 8 || len > S || (len % 8)) return false;
+  }
+  d.T = r.row(B);
+  d.Srows = d.ldS;
+  return true;
+}
+
+// The attention of a pass as independent sub-problems for the kernels that take a B x S rectangle: the whole
+// pass (rectangular), or one sequence at a time (ragged; each keeps its scores as [heads][len][ld(len)] at the
+// start of its slots).  tok = first token row, slot = first element of its score slots.
+struct Sub { Dims d; long tok, slot; };
+inline int n_subs(const Dims& d, const Rag& r) { (void)d; return r.on() ? r.B : 1; }
+inline Sub sub_at(const Dims& d, const Rag& r, int i) {
+  Sub u;
+  u.d = d; u.tok = 0; u.slot = 0;
+  if (r.on()) {
+    const int len = r.len(i);
+    u.d.B = 1; u.d.S = len; u.d.ldS = pg_score_ld(len); u.d.Srows = len; u.d.T = len; u.d.Z = d.nh;
+    u.tok = r.row(i);
+    u.slot = (long)i * d.nh * d.Srows * d.ldS;
+  }
+  return u;
 }
 
 struct ParamView {
@@ -155,18 +201,26 @@ struct G {
   int dw_pair(const pg_gemm_desc& d0, const pg_gemm_desc& d1) const { return pg_gemm_pair(&d0, &d1, st); }
   // Batched over (b, head).  Operands living in a [T][ld] activation buffer are addressed with
   // (outer = S*ld, inner = 64); score-shaped operands with (outer = nh*S*ldS, inner = S*ldS).
+  // (A2, B2): optional second reduction segment in the layout of (A, B), N <= 64 products only.
+  // rag (fused bf16 passes over ragged sequences, N = 64, M = K = S): the token-row operands follow seq_off.
   int bat(const Dims& dm, const void* A, bool ak, long lda, bool a_score, const void* B, bool bk, long ldb, bool b_score,
-          void* C, int cdt, long ldc, bool c_score, int M, int N, int K, float alpha, float beta) const {
+          void* C, int cdt, long ldc, bool c_score, int M, int N, int K, float alpha, float beta, const Rag* rag = nullptr,
+          const void* A2 = nullptr, const void* B2 = nullptr) const {
     pg_gemm_desc d;
     memset(&d, 0, sizeof(d));
     d.A = A; d.B = B; d.C = C; d.dtype = dtype; d.c_dtype = cdt; d.a_kmajor = ak; d.b_kmajor = bk;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
     d.batch = (int)dm.Z; d.batch_inner = dm.nh;
-    const long so = (long)dm.nh * dm.S * dm.ldS, si = (long)dm.S * dm.ldS;
+    const long so = (long)dm.nh * dm.Srows * dm.ldS, si = (long)dm.Srows * dm.ldS;
     d.sAo = a_score ? so : (long)dm.S * lda; d.sAi = a_score ? si : 64;
     d.sBo = b_score ? so : (long)dm.S * ldb; d.sBi = b_score ? si : 64;
     d.sCo = c_score ? so : (long)dm.S * ldc; d.sCi = c_score ? si : 64;
     d.alpha = alpha; d.beta = beta;
+    if (A2) { d.A2 = A2; d.B2 = B2; d.K2 = K; }
+    if (rag && rag->on()) {
+      d.seq_off = rag->off; d.seq_tok0 = rag->tok0;
+      d.seq_ops = (a_score ? 0 : 1) | (b_score ? 0 : 2) | (c_score ? 0 : 4);
+    }
     return pg_gemm(&d, st);
   }
 };
@@ -242,24 +296,36 @@ Slots layer_slots(char* base, const StashLayout& sl, const Dims& d, int l) {
 struct StashView {
   Dims dl;
   StashLayout sl;
-  long row0;
+  long row0;     // first sequence of the view
+  long tok_off;  // its first token row inside the stash
 };
-bool make_view(const pg_model_cfg* cfg, int dtype, int B, int S, int stash_rows, int stash_row0, StashView& v) {
-  const int rows = stash_rows > 0 ? stash_rows : B;
-  if (stash_row0 < 0 || stash_row0 + B > rows) return false;
-  if (!make_dims(cfg, dtype, rows, S, v.dl)) return false;
-  v.sl = stash_layout(v.dl);
+// pass: the viewing pass's dims (its T rows must fit).  Ragged: the stash holds view_T token rows (0 = the pass's
+// own count) and the view starts at token row tok_abs; rectangular: rows * S token rows, view at row0 * S.
+bool make_view(const pg_model_cfg* cfg, int dtype, const Dims& pass, const Rag& r, int stash_rows, int stash_row0, int view_T,
+               long tok_abs, StashView& v) {
+  const int rows = stash_rows > 0 ? stash_rows : pass.B;
+  if (stash_row0 < 0 || stash_row0 + pass.B > rows) return false;
+  if (!make_dims(cfg, dtype, rows, pass.S, v.dl)) return false;
   v.row0 = stash_row0;
+  if (r.on()) {
+    v.dl.T = view_T > 0 ? view_T : pass.T;
+    v.dl.Srows = v.dl.ldS;
+    v.tok_off = tok_abs;
+    if (tok_abs < 0 || tok_abs + pass.T > v.dl.T) return false;
+  } else {
+    v.tok_off = (long)stash_row0 * pass.S;
+  }
+  v.sl = stash_layout(v.dl);
   return true;
 }
 Slots view_slots(char* base, const StashView& v, int l) {
   Slots s = layer_slots(base, v.sl, v.dl, l);
   const Dims& d = v.dl;
-  const long t = v.row0 * d.S * d.es;
+  const long t = v.tok_off * d.es;
   s.x += t * d.H; s.y += t * d.H; s.ctx += t * d.H; s.a += t * d.H; s.h += t * d.H; s.f += t * d.H;
   s.qkv += t * 3 * d.H;
   s.u += t * d.I; s.gu += t * d.I;
-  s.ss += v.row0 * d.nh * d.S * d.ldS * d.es;
+  s.ss += v.row0 * d.nh * d.Srows * d.ldS * d.es;
   return s;
 }
 
@@ -333,22 +399,38 @@ extern "C" int64_t pg_stash_bytes(const pg_model_cfg* cfg, int dtype, int B, int
   if (!make_dims(cfg, dtype, B, S, d)) return -1;
   return stash_layout(d).total_bytes;
 }
+extern "C" int64_t pg_workspace_bytes_ragged(const pg_model_cfg* cfg, int dtype, int B, int max_len, int T) {
+  Dims d;
+  if (T <= 0 || !make_dims(cfg, dtype, B, max_len, d)) return -1;
+  d.T = T; d.Srows = d.ldS;
+  return ws_layout(d, nullptr).total_bytes;
+}
+extern "C" int64_t pg_stash_bytes_ragged(const pg_model_cfg* cfg, int dtype, int B, int max_len, int T) {
+  Dims d;
+  if (T <= 0 || !make_dims(cfg, dtype, B, max_len, d)) return -1;
+  d.T = T; d.Srows = d.ldS;
+  return stash_layout(d).total_bytes;
+}
 
 // ------------------------------------------------------------------ forward
-// Packed form (seq_off != NULL; inference, bf16, ids only): the B sequences have their own lengths
+// Packed inference form (seq_off != NULL; bf16, ids only, nothing stashed): the B sequences have their own lengths
 // seq_off[b+1] - seq_off[b] <= S and lie back to back in T_packed token rows; every token-wise kernel
 // runs on T_packed rows, attention walks each sequence's own keys.  Buffers are laid out for B x S.
+// Ragged form (rg != NULL): the same with every option of the rectangular pass (stash, fp32, x_in); buffers are
+// laid out for the packed token count.
 static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const int64_t* ids,
                         const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes, void* stash,
                         void* hidden_out, void* emb_sum_out, void* stream, const int32_t* seq_off, const int32_t* pos_ids,
-                        int T_packed) {
+                        int T_packed, const pg_ragged* rg) {
   Dims d;
-  if (!make_dims(cfg, dtype, B, S, d) || !p || !p->master || (!ids && !x_in) || !workspace) return PG_ERR_ARG;
+  Rag rag;
+  if (!make_dims_rg(cfg, dtype, B, S, rg, d, rag) || !p || !p->master || (!ids && !x_in) || !workspace) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   if (!stash && !hidden_out) return PG_ERR_ARG;
   if (d.ldS > 1024 && !(!stash && dtype == PG_BF16 && S <= 2048)) return PG_ERR_UNSUPPORTED;
-  if (seq_off && (!ids || !pos_ids || stash || emb_sum_out || T_packed <= 0 || T_packed > d.T)) return PG_ERR_ARG;
+  if (seq_off && (rg || !ids || !pos_ids || stash || emb_sum_out || T_packed <= 0 || T_packed > d.T)) return PG_ERR_ARG;
   if (seq_off && !(dtype == PG_BF16 && S <= 2048)) return PG_ERR_UNSUPPORTED;
+  if (rag.on() && (rag.tok0 != 0 || (ids && !pos_ids))) return PG_ERR_ARG;  // a forward owns all of its token rows
   Workspace w = ws_layout(d, (char*)workspace);
   if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -356,6 +438,7 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
   G g{dtype, st};
   const int es = d.es, H = d.H, I = d.I, T = seq_off ? T_packed : (int)d.T;
   StashLayout sl = stash_layout(d);
+  const bool fused = dtype == PG_BF16 && S <= 2048;
 
   char* x = stash ? (char*)stash + sl.xs : w.x0;
   if (seq_off) {
@@ -363,12 +446,17 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
                           pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)),
                           pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)),
                           cfg->ln_eps, x, T, H, st));
+  } else if (ids && rag.on()) {
+    CK(pg_embed_ln2_packed(dtype, ids, pos_ids, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)),
+                           pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)),
+                           pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)),
+                           cfg->ln_eps, x, emb_sum_out, T, H, st));
   } else if (ids) {
     CK(pg_embed_ln2(dtype, ids, pv.m(pg_param_offset_global(cfg, PG_P_WORD_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_POS_EMB)),
                     pv.m(pg_param_offset_global(cfg, PG_P_TYPE_EMB)), pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_G)),
                     pv.m(pg_param_offset_global(cfg, PG_P_EMB_LN_B)), cfg->ln_eps, x, emb_sum_out, B, S, H, st));
   } else {
-    if (hipMemcpyAsync(x, x_in, (size_t)d.T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+    if (hipMemcpyAsync(x, x_in, (size_t)T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
   for (int l = 0; l < d.L; ++l) {
     Slots s;
@@ -384,20 +472,29 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
              pv.m(pv.lo(l, PG_L_BQ))));
     if (seq_off) {
       CK(pg_attention_fwd_packed(dtype, s.qkv, mask, s.ctx, seq_off, B, S, d.nh, 3 * H, H, st));
-    } else if (!stash && dtype == PG_BF16 && S <= 2048) {
+    } else if (!stash && fused && rag.on()) {
+      CK(pg_attention_fwd_packed(dtype, s.qkv, mask, s.ctx, rag.off, B, S, d.nh, 3 * H, H, st));
+    } else if (!stash && fused) {
       // nothing is kept for a backward: fused attention, no score matrix in HBM
       CK(pg_attention_fwd(dtype, s.qkv, mask, s.ctx, B, S, d.nh, 3 * H, H, st));
-    } else if (stash && dtype == PG_BF16 && S <= 2048) {
+    } else if (fused && rag.on()) {
+      CK(pg_attention_fwd_p_ragged(dtype, s.qkv, mask, s.ss, s.ctx, rag.off, B, S, 0, d.nh, 3 * H, H, st));
+    } else if (fused) {
       // fused attention that also writes P once for the backward passes
       CK(pg_attention_fwd_p(dtype, s.qkv, mask, s.ss, s.ctx, B, S, d.nh, 3 * H, H, st));
     } else {
-      // scores = Q K^T / 8
-      CK(g.bat(d, s.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-               0.125f, 0.f));
-      CK(pg_softmax_fwd(dtype, w.sc0, mask, s.ss, B, d.nh, S, st));
-      // ctx = P V
-      CK(g.bat(d, s.ss, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, s.ctx, dtype, H, false, S, 64, S,
-               1.f, 0.f));
+      for (int i = 0; i < n_subs(d, rag); ++i) {
+        const Sub u = sub_at(d, rag, i);
+        const char* qkv = s.qkv + u.tok * 3 * H * es;
+        char* ss = s.ss + u.slot * es;
+        // scores = Q K^T / 8
+        CK(g.bat(u.d, qkv, true, 3 * H, false, off(qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, u.d.ldS, true, u.d.S, u.d.S,
+                 64, 0.125f, 0.f));
+        CK(pg_softmax_fwd(dtype, w.sc0, mask ? mask + u.tok : nullptr, ss, u.d.B, d.nh, u.d.S, st));
+        // ctx = P V
+        CK(g.bat(u.d, ss, true, u.d.ldS, true, off(qkv, 2 * H, es), false, 3 * H, false, s.ctx + u.tok * H * es, dtype, H, false,
+                 u.d.S, 64, u.d.S, 1.f, 0.f));
+      }
     }
     // a = ctx Wo^T + bo + x ; h = LN1(a)
     CK(g.run(s.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, s.a, dtype, H, T, H, H, 1.f, 0.f, pv.m(pv.lo(l, PG_L_BO)),
@@ -412,7 +509,7 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
     x = s.y;
   }
   if (stash && hidden_out) {
-    if (hipMemcpyAsync(hidden_out, x, (size_t)d.T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
+    if (hipMemcpyAsync(hidden_out, x, (size_t)T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
   return PG_OK;
 }
@@ -421,7 +518,7 @@ extern "C" int pg_encoder_forward(const pg_model_cfg* cfg, const pg_params* p, i
                                   const void* x_in, const float* mask, void* workspace, int64_t workspace_bytes,
                                   void* stash, void* hidden_out, void* emb_sum_out, void* stream) {
   return forward_impl(cfg, p, dtype, B, S, ids, x_in, mask, workspace, workspace_bytes, stash, hidden_out, emb_sum_out, stream,
-                      nullptr, nullptr, 0);
+                      nullptr, nullptr, 0, nullptr);
 }
 
 extern "C" int pg_encoder_forward_packed(const pg_model_cfg* cfg, const pg_params* p, int dtype, int nseq, int max_len,
@@ -430,7 +527,16 @@ extern "C" int pg_encoder_forward_packed(const pg_model_cfg* cfg, const pg_param
                                          void* stream) {
   if (!seq_off || !hidden_out) return PG_ERR_ARG;
   return forward_impl(cfg, p, dtype, nseq, max_len, ids, nullptr, mask, workspace, workspace_bytes, nullptr, hidden_out, nullptr,
-                      stream, seq_off, pos_ids, T);
+                      stream, seq_off, pos_ids, T, nullptr);
+}
+
+extern "C" int pg_encoder_forward_ragged(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, const pg_ragged* rg,
+                                         const int64_t* ids, const int32_t* pos_ids, const void* x_in, const float* mask,
+                                         void* workspace, int64_t workspace_bytes, void* stash, void* hidden_out,
+                                         void* emb_sum_out, void* stream) {
+  if (!rg) return PG_ERR_ARG;
+  return forward_impl(cfg, p, dtype, B, rg->max_len, ids, x_in, mask, workspace, workspace_bytes, stash, hidden_out, emb_sum_out,
+                      stream, nullptr, pos_ids, 0, rg);
 }
 
 // MLM head: t = LN(gelu(hidden W^T + b)) ; logits = t word^T + bias
@@ -457,12 +563,13 @@ extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dt
 extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                    void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
                                    void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                                   int stash_rows, int stash_row0, int grad_row0) {
+                                   int stash_rows, int stash_row0, int grad_row0, const pg_ragged* rg) {
   (void)mask;
   Dims d;
-  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
+  Rag rag;
+  if (!make_dims_rg(cfg, dtype, B, S, rg, d, rag) || !p || !stash || !d_hidden || !workspace) return PG_ERR_ARG;
   StashView sv;
-  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
+  if (!make_view(cfg, dtype, d, rag, stash_rows, stash_row0, rg ? rg->stash_T : 0, rag.tok0, sv)) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS, save = flags & PG_BWD_SAVE_ADJOINTS;
   if (grads && !p->grad) return PG_ERR_ARG;
   if (save && !adj_stash) return PG_ERR_ARG;
@@ -477,10 +584,12 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
   const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
   StashLayout sl = stash_layout(d);
   const size_t th_bytes = (size_t)d.T * H * es;
+  const bool fused = dtype == PG_BF16 && S <= 2048;
+  const Rag* frag = rag.on() ? &rag : nullptr;
   // parameter gradients are taken from the sequences grad_row0.. only (the others ride along for their input
   // gradient and adjoints: the gradient-penalty interpolates in front of the real and fake rows)
   if (grad_row0 < 0 || grad_row0 >= B) return PG_ERR_ARG;
-  const long r0 = (long)grad_row0 * S;
+  const long r0 = rag.on() ? rag.row(grad_row0) : (long)grad_row0 * S;
   const int Tg = T - (int)r0;
   auto ln_bwd = [&](const char* x, const char* dyp, const float* gamma, char* out, float* gG, float* gB, float* gX) -> int {
     if (!grads) return pg_layernorm_bwd(dtype, x, dyp, gamma, cfg->ln_eps, out, nullptr, nullptr, nullptr, w.ln_partial, T, H, st);
@@ -532,19 +641,32 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     // dctx = da Wo   (dWo = da^T ctx waits for dWqkv below: 64 + 192 tiles fill the chip together)
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
-    if (dtype == PG_BF16 && S <= 2048) {
-      CK(pg_attention_bwd_dq(dtype, s.qkv, s.ss, s.ctx, a.ctx, a.ss, a.qkv, B, S, d.nh, 3 * H, H, 3 * H, st));
+    if (fused) {
+      if (rag.on())
+        CK(pg_attention_bwd_dq_ragged(dtype, s.qkv, s.ss, s.ctx, a.ctx, a.ss, a.qkv, rag.off, B, S, rag.tok0, d.nh, 3 * H, H,
+                                      3 * H, st));
+      else
+        CK(pg_attention_bwd_dq(dtype, s.qkv, s.ss, s.ctx, a.ctx, a.ss, a.qkv, B, S, d.nh, 3 * H, H, 3 * H, st));
+      CK(g.bat(d, a.ss, false, d.ldS, true, s.qkv, false, 3 * H, false, off(a.qkv, H, es), dtype, 3 * H, false, S, 64, S,
+               0.125f, 0.f, frag));
+      CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+               0.f, frag));
     } else {
-      CK(g.bat(d, a.ctx, true, H, false, off(s.qkv, 2 * H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-               1.f, 0.f));
-      CK(pg_softmax_bwd(dtype, w.sc0, s.ss, a.ss, (int)d.Z, S, st));
-      CK(g.bat(d, a.ss, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, a.qkv, dtype, 3 * H, false, S, 64, S,
-               0.125f, 0.f));
+      for (int i = 0; i < n_subs(d, rag); ++i) {
+        const Sub u = sub_at(d, rag, i);
+        const char* qkv = s.qkv + u.tok * 3 * H * es;
+        const char* ss = s.ss + u.slot * es;
+        char* ass = a.ss + u.slot * es;
+        char* aqkv = a.qkv + u.tok * 3 * H * es;
+        const char* actx = a.ctx + u.tok * H * es;
+        const int Su = u.d.S, ld = u.d.ldS;
+        CK(g.bat(u.d, actx, true, H, false, off(qkv, 2 * H, es), true, 3 * H, false, w.sc0, PG_F32, ld, true, Su, Su, 64, 1.f, 0.f));
+        CK(pg_softmax_bwd(dtype, w.sc0, ss, ass, (int)u.d.Z, Su, st));
+        CK(g.bat(u.d, ass, true, ld, true, off(qkv, H, es), false, 3 * H, false, aqkv, dtype, 3 * H, false, Su, 64, Su, 0.125f, 0.f));
+        CK(g.bat(u.d, ass, false, ld, true, qkv, false, 3 * H, false, off(aqkv, H, es), dtype, 3 * H, false, Su, 64, Su, 0.125f, 0.f));
+        CK(g.bat(u.d, ss, false, ld, true, actx, false, H, false, off(aqkv, 2 * H, es), dtype, 3 * H, false, Su, 64, Su, 1.f, 0.f));
+      }
     }
-    CK(g.bat(d, a.ss, false, d.ldS, true, s.qkv, false, 3 * H, false, off(a.qkv, H, es), dtype, 3 * H, false, S, 64, S,
-             0.125f, 0.f));
-    CK(g.bat(d, s.ss, false, d.ldS, true, a.ctx, false, H, false, off(a.qkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
-             0.f));
     if (grads) {
       // dW2 = df^T gu, dW1 = du^T h, dWqkv = dqkv^T x, dWo = da^T ctx: 64 + 64 + 48 + 16 tiles of 256x256
       const long oH = r0 * H * es, oI = r0 * I * es, oQ = r0 * 3 * H * es;
@@ -569,11 +691,12 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
 // ------------------------------------------------------------------ GP tangent-forward pass
 extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                               const void* xdot_in, void* tan_stash, void* hdot_out, void* workspace, int64_t workspace_bytes,
-                              void* stream, int stash_rows, int stash_row0) {
+                              void* stream, int stash_rows, int stash_row0, const pg_ragged* rg) {
   Dims d;
-  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !xdot_in || !tan_stash || !workspace) return PG_ERR_ARG;
+  Rag rag;
+  if (!make_dims_rg(cfg, dtype, B, S, rg, d, rag) || !p || !stash || !xdot_in || !tan_stash || !workspace) return PG_ERR_ARG;
   StashView sv;
-  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
+  if (!make_view(cfg, dtype, d, rag, stash_rows, stash_row0, rg ? rg->stash_T : 0, rag.tok0, sv)) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   Workspace w = ws_layout(d, (char*)workspace);
   if (w.total_bytes > workspace_bytes) return PG_ERR_WORKSPACE;
@@ -591,19 +714,28 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
     CK(g.run(t.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, t.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f));
     if (fused_gp_attention(dtype, S)) {
       // one sweep; the score slot of the tangent stash keeps only rho = rowsum(P Sdot)
-      CK(pg_attention_jvp(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, (float*)t.ss, B, S, d.nh, 3 * H, H, H, st));
+      if (rag.on())
+        CK(pg_attention_jvp_ragged(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, (float*)t.ss, rag.off, B, S, rag.tok0, d.nh, 3 * H,
+                                   H, H, st));
+      else
+        CK(pg_attention_jvp(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, (float*)t.ss, B, S, d.nh, 3 * H, H, H, st));
     } else {
-      // Sdot = (Qdot K^T + Q Kdot^T)/8
-      CK(g.bat(d, t.qkv, true, 3 * H, false, off(s.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-               0.125f, 0.f));
-      CK(g.bat(d, s.qkv, true, 3 * H, false, off(t.qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64,
-               0.125f, 1.f));
-      CK(pg_softmax_jvp(dtype, w.sc0, s.ss, t.ss, w.ss0, (int)d.Z, S, st));
-      // ctxdot = Pdot V + P Vdot
-      CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
-               0.f));
-      CK(g.bat(d, s.ss, true, d.ldS, true, off(t.qkv, 2 * H, es), false, 3 * H, false, t.ctx, dtype, H, false, S, 64, S, 1.f,
-               1.f));
+      for (int i = 0; i < n_subs(d, rag); ++i) {
+        const Sub u = sub_at(d, rag, i);
+        const char* qkv = s.qkv + u.tok * 3 * H * es;
+        const char* tqkv = t.qkv + u.tok * 3 * H * es;
+        const char* ss = s.ss + u.slot * es;
+        char* tss = t.ss + u.slot * es;
+        char* tctx = t.ctx + u.tok * H * es;
+        const int Su = u.d.S, ld = u.d.ldS;
+        // Sdot = (Qdot K^T + Q Kdot^T)/8
+        CK(g.bat(u.d, tqkv, true, 3 * H, false, off(qkv, H, es), true, 3 * H, false, w.sc0, PG_F32, ld, true, Su, Su, 64, 0.125f, 0.f));
+        CK(g.bat(u.d, qkv, true, 3 * H, false, off(tqkv, H, es), true, 3 * H, false, w.sc0, PG_F32, ld, true, Su, Su, 64, 0.125f, 1.f));
+        CK(pg_softmax_jvp(dtype, w.sc0, ss, tss, w.ss0, (int)u.d.Z, Su, st));
+        // ctxdot = Pdot V + P Vdot
+        CK(g.bat(u.d, w.ss0, true, ld, true, off(qkv, 2 * H, es), false, 3 * H, false, tctx, dtype, H, false, Su, 64, Su, 1.f, 0.f));
+        CK(g.bat(u.d, ss, true, ld, true, off(tqkv, 2 * H, es), false, 3 * H, false, tctx, dtype, H, false, Su, 64, Su, 1.f, 1.f));
+      }
     }
     CK(g.run(t.ctx, true, H, pv.w(pv.lo(l, PG_L_WO)), true, H, t.a, dtype, H, T, H, H, 1.f, 0.f, nullptr, t.x, H));
     CK(pg_layernorm_jvp(dtype, s.a, t.a, pv.m(pv.lo(l, PG_L_LN1_G)), cfg->ln_eps, t.h, T, H, st));
@@ -623,12 +755,14 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
 extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                     const void* adj_stash, const void* tan_stash, int flags, void* xbar_out,
                                     void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,
-                                    int stash_rows, int stash_row0, int adj_rows) {
+                                    int stash_rows, int stash_row0, int adj_rows, const pg_ragged* rg) {
   Dims d;
-  if (!make_dims(cfg, dtype, B, S, d) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
+  Rag rag;
+  if (!make_dims_rg(cfg, dtype, B, S, rg, d, rag) || !p || !stash || !adj_stash || !tan_stash || !workspace) return PG_ERR_ARG;
   StashView sv, sva;
-  if (!make_view(cfg, dtype, B, S, stash_rows, stash_row0, sv)) return PG_ERR_ARG;
-  if (!make_view(cfg, dtype, B, S, adj_rows, 0, sva)) return PG_ERR_ARG;  // adjoints of a pass over adj_rows >= B sequences
+  if (!make_view(cfg, dtype, d, rag, stash_rows, stash_row0, rg ? rg->stash_T : 0, rag.tok0, sv)) return PG_ERR_ARG;
+  // adjoints of a pass over adj_rows >= B sequences, of which this pass's are the first
+  if (!make_view(cfg, dtype, d, rag, adj_rows, 0, rg ? rg->adj_T : 0, 0, sva)) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS;
   if (grads && !p->grad) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
@@ -642,6 +776,7 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
   const int es = d.es, H = d.H, I = d.I, T = (int)d.T;
   StashLayout sl = stash_layout(d);
   const size_t th_bytes = (size_t)d.T * H * es;
+  const Rag* frag = rag.on() ? &rag : nullptr;
 
   char* ybar = nullptr;  // second-order adjoint of the layer output (zero above the last layer)
   DwQueue dwq;
@@ -671,32 +806,51 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     // ctxbar = abar Wo
     CK(g.run(wa, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, w.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention second order
-    const char* v = off(s.qkv, 2 * H, es);
-    const char* vdot = off(t.qkv, 2 * H, es);
     if (fused_gp_attention(dtype, S)) {
-      CK(pg_attention_bwd2(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, a.ctx, w.ctx, (const float*)t.ss, w.ss0 /*Sbar*/,
-                           w.ss1 /*Pdot*/, B, S, d.nh, 3 * H, H, st));
+      if (rag.on())
+        CK(pg_attention_bwd2_ragged(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, a.ctx, w.ctx, (const float*)t.ss, w.ss0 /*Sbar*/,
+                                    w.ss1 /*Pdot*/, rag.off, B, S, rag.tok0, d.nh, 3 * H, H, st));
+      else
+        CK(pg_attention_bwd2(dtype, s.qkv, t.qkv, s.ss, s.ctx, t.ctx, a.ctx, w.ctx, (const float*)t.ss, w.ss0 /*Sbar*/,
+                             w.ss1 /*Pdot*/, B, S, d.nh, 3 * H, H, st));
+      // qbar = (Sbar K + gS Kdot)/8 ; kbar = (Sbar^T Q + gS^T Qdot)/8 ; vbar = P^T ctxbar + Pdot^T gctx:
+      // each one launch over two reduction segments
+      CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, wqkv, dtype, 3 * H, false, S, 64, S,
+               0.125f, 0.f, frag, a.ss, off(t.qkv, H, es)));
+      CK(g.bat(d, w.ss0, false, d.ldS, true, s.qkv, false, 3 * H, false, off(wqkv, H, es), dtype, 3 * H, false, S, 64, S,
+               0.125f, 0.f, frag, a.ss, t.qkv));
+      // (ctxbar and gctx have row stride H: the two segments of vbar must share a leading dimension, they do)
+      CK(g.bat(d, s.ss, false, d.ldS, true, w.ctx, false, H, false, off(wqkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
+               0.f, frag, w.ss1, a.ctx));
     } else {
-      CK(g.bat(d, a.ctx, true, H, false, v, true, 3 * H, false, w.sc0, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // gP
-      CK(g.bat(d, w.ctx, true, H, false, v, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 0.f));      // X
-      CK(g.bat(d, a.ctx, true, H, false, vdot, true, 3 * H, false, w.sc1, PG_F32, d.ldS, true, S, S, 64, 1.f, 1.f));
-      CK(pg_softmax_bwd2(dtype, s.ss, t.ss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)d.Z, S, st));
+      for (int i = 0; i < n_subs(d, rag); ++i) {
+        const Sub u = sub_at(d, rag, i);
+        const char* qkv = s.qkv + u.tok * 3 * H * es;
+        const char* tqkv = t.qkv + u.tok * 3 * H * es;
+        const char* ss = s.ss + u.slot * es;
+        const char* tss = t.ss + u.slot * es;
+        const char* ass = a.ss + u.slot * es;
+        const char* actx = a.ctx + u.tok * H * es;
+        const char* cbar = w.ctx + u.tok * H * es;
+        char* qb = wqkv + u.tok * 3 * H * es;
+        const char* v = off(qkv, 2 * H, es);
+        const char* vdot = off(tqkv, 2 * H, es);
+        const int Su = u.d.S, ld = u.d.ldS;
+        CK(g.bat(u.d, actx, true, H, false, v, true, 3 * H, false, w.sc0, PG_F32, ld, true, Su, Su, 64, 1.f, 0.f));      // gP
+        CK(g.bat(u.d, cbar, true, H, false, v, true, 3 * H, false, w.sc1, PG_F32, ld, true, Su, Su, 64, 1.f, 0.f));      // X
+        CK(g.bat(u.d, actx, true, H, false, vdot, true, 3 * H, false, w.sc1, PG_F32, ld, true, Su, Su, 64, 1.f, 1.f));
+        CK(pg_softmax_bwd2(dtype, ss, tss, w.sc0, w.sc1, w.ss0 /*Sbar*/, w.ss1 /*Pdot*/, (int)u.d.Z, Su, st));
+        // qbar = (Sbar K + gS Kdot)/8
+        CK(g.bat(u.d, w.ss0, true, ld, true, off(qkv, H, es), false, 3 * H, false, qb, dtype, 3 * H, false, Su, 64, Su, 0.125f, 0.f));
+        CK(g.bat(u.d, ass, true, ld, true, off(tqkv, H, es), false, 3 * H, false, qb, dtype, 3 * H, false, Su, 64, Su, 0.125f, 1.f));
+        // kbar = (Sbar^T Q + gS^T Qdot)/8
+        CK(g.bat(u.d, w.ss0, false, ld, true, qkv, false, 3 * H, false, off(qb, H, es), dtype, 3 * H, false, Su, 64, Su, 0.125f, 0.f));
+        CK(g.bat(u.d, ass, false, ld, true, tqkv, false, 3 * H, false, off(qb, H, es), dtype, 3 * H, false, Su, 64, Su, 0.125f, 1.f));
+        // vbar = P^T ctxbar + Pdot^T gctx
+        CK(g.bat(u.d, ss, false, ld, true, cbar, false, H, false, off(qb, 2 * H, es), dtype, 3 * H, false, Su, 64, Su, 1.f, 0.f));
+        CK(g.bat(u.d, w.ss1, false, ld, true, actx, false, H, false, off(qb, 2 * H, es), dtype, 3 * H, false, Su, 64, Su, 1.f, 1.f));
+      }
     }
-    // qbar = (Sbar K + gS Kdot)/8
-    CK(g.bat(d, w.ss0, true, d.ldS, true, off(s.qkv, H, es), false, 3 * H, false, wqkv, dtype, 3 * H, false, S, 64, S,
-             0.125f, 0.f));
-    CK(g.bat(d, a.ss, true, d.ldS, true, off(t.qkv, H, es), false, 3 * H, false, wqkv, dtype, 3 * H, false, S, 64, S,
-             0.125f, 1.f));
-    // kbar = (Sbar^T Q + gS^T Qdot)/8
-    CK(g.bat(d, w.ss0, false, d.ldS, true, s.qkv, false, 3 * H, false, off(wqkv, H, es), dtype, 3 * H, false, S, 64, S,
-             0.125f, 0.f));
-    CK(g.bat(d, a.ss, false, d.ldS, true, t.qkv, false, 3 * H, false, off(wqkv, H, es), dtype, 3 * H, false, S, 64, S,
-             0.125f, 1.f));
-    // vbar = P^T ctxbar + Pdot^T gctx
-    CK(g.bat(d, s.ss, false, d.ldS, true, w.ctx, false, H, false, off(wqkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
-             0.f));
-    CK(g.bat(d, w.ss1, false, d.ldS, true, a.ctx, false, H, false, off(wqkv, 2 * H, es), dtype, 3 * H, false, S, 64, S, 1.f,
-             1.f));
     if (grads) {
       const pg_gemm_desc dws[4] = {g.dw_desc(wf, s.gu, pv.g(pv.lo(l, PG_L_W2)), H, I, T, a.f, t.gu),
                                    g.dw_desc(wu, s.h, pv.g(pv.lo(l, PG_L_W1)), I, H, T, a.u, t.h),

@@ -62,6 +62,10 @@ struct GemmArgs {
   int vec_ok;
   const void* A2; const void* B2; int K2;  // optional second reduction segment (same layout and strides)
   int group_m;  // tile rows per group of the grouped tile order (1 = row-major)
+  // Ragged batches (128x64-tile kernel only): batch (zo, zi) is sequence zo, head zi.  Its token-row operands
+  // (bits of seq_ops: 1 = A, 2 = B, 4 = C) start at row seq_off[zo] - seq_tok0 of their buffers and M = K =
+  // seq_off[zo+1] - seq_off[zo]; score-shaped operands keep their batch strides.
+  const int* seq_off; int seq_tok0; int seq_ops;
 };
 
 // ---- global -> register staging of one operand tile -------------------------------------
@@ -1032,7 +1036,7 @@ constexpr int NB_ELEMS = 64 * GBK;  // 4096 bf16 = 8 KiB
 
 template <bool KMAJOR>
 __device__ __forceinline__ void glds_stage_b64(const bf16_t* __restrict__ base, long ld, int n0, int n_max, int k0,
-                                               bf16_t* lds_tile, int wid, int lane) {
+                                               bf16_t* lds_tile, int wid, int lane, int k_max) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int i = wid * 2 + j;            // wave instruction 0..7: 8 rows of 128 B
@@ -1046,7 +1050,9 @@ __device__ __forceinline__ void glds_stage_b64(const bf16_t* __restrict__ base, 
     } else {
       int n = n0 + c * 8;
       n = n <= n_max - 8 ? n : n_max - 8;
-      src = base + (long)(k0 + row) * ld + n;
+      int kr = k0 + row;  // (a ragged reduction extent ends inside the tile: rows past it meet zeros of A)
+      kr = kr < k_max ? kr : k_max - 1;
+      src = base + (long)kr * ld + n;
     }
     __builtin_amdgcn_global_load_lds(src, lds_tile + i * 512, 16, 0, 0);
   }
@@ -1059,10 +1065,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) 
   const int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gxy * gridDim.z);
   const int z = lid / gxy, txy = lid % gxy;
   const int zo = z / g.batch_inner, zi = z % g.batch_inner;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + zo * g.sAo + zi * g.sAi;
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + zo * g.sBo + zi * g.sBi;
-  TC* Cp = reinterpret_cast<TC*>(g.C) + zo * g.sCo + zi * g.sCi;
   const int bm = (txy / gridDim.x) * BM, bn = (txy % gridDim.x) * 64;
+  long oA = zo * g.sAo, oB = zo * g.sBo, oC = zo * g.sCo;
+  GemmArgs gl = g;  // (M, K of this batch)
+  if (g.seq_off) {
+    const int a0 = g.seq_off[zo];
+    const long r0 = a0 - g.seq_tok0;
+    gl.M = gl.K = g.seq_off[zo + 1] - a0;
+    if (bm >= gl.M) return;
+    if (g.seq_ops & 1) oA = r0 * g.lda;
+    if (g.seq_ops & 2) oB = r0 * g.ldb;
+    if (g.seq_ops & 4) oC = r0 * g.ldc;
+  }
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + oA + zi * g.sAi;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + oB + zi * g.sBi;
+  const bf16_t* A2 = g.K2 > 0 ? reinterpret_cast<const bf16_t*>(g.A2) + oA + zi * g.sAi : nullptr;
+  const bf16_t* B2 = g.K2 > 0 ? reinterpret_cast<const bf16_t*>(g.B2) + oB + zi * g.sBi : nullptr;
+  TC* Cp = reinterpret_cast<TC*>(g.C) + oC + zi * g.sCi;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, gq = lane >> 4, qq = r >> 2, pp = r & 3;
@@ -1104,16 +1123,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) 
 
   const unsigned smem_addr = lds_addr(smem);
   constexpr int BUF = GT_ELEMS + NB_ELEMS;
-  const int nt = g.K / GBK;
-  glds_stage<AK>(A, g.lda, bm, g.M, 0, smem, wid, lane);
-  glds_stage_b64<BK_>(B, g.ldb, bn, g.N, 0, smem + GT_ELEMS, wid, lane);
+  // k-tiles [0, nt1) come from (A, B), k-tiles [nt1, nt) from the optional second segment (A2, B2); a ragged
+  // batch has the same extent in both
+  const int nt1 = (gl.K + GBK - 1) / GBK;
+  const int K2 = g.K2 > 0 ? (g.seq_off ? gl.K : g.K2) : 0;
+  const int nt = nt1 + (K2 + GBK - 1) / GBK;
+  auto stage = [&](int t, bf16_t* dst) {
+    const bool second = t >= nt1;
+    const int k0 = (second ? t - nt1 : t) * GBK;
+    glds_stage<AK>(second ? A2 : A, g.lda, bm, gl.M, k0, dst, wid, lane);
+    glds_stage_b64<BK_>(second ? B2 : B, g.ldb, bn, g.N, k0, dst + GT_ELEMS, wid, lane, second ? K2 : gl.K);
+  };
+  stage(0, smem);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) {
-      bf16_t* na = smem + ((t + 1) & 1) * BUF;
-      glds_stage<AK>(A, g.lda, bm, g.M, (t + 1) * GBK, na, wid, lane);
-      glds_stage_b64<BK_>(B, g.ldb, bn, g.N, (t + 1) * GBK, na + GT_ELEMS, wid, lane);
-    }
+    if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * BUF);
     const unsigned la = smem_addr + (t & 1) * BUF * 2;
     const unsigned lb = la + GT_ELEMS * 2;
     u32x4 af[2][2], bf[2][4];  // [kk][tile]
@@ -1162,7 +1186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) 
                                                               __builtin_bit_cast(bf16x8_t, af[kk][i]), acc[i][j], 0, 0, 0);
     __syncthreads();
   }
-  gemm_epilogue<bf16_t, TC, 2>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + 64 <= g.N, bm + wid * 32, bn, lane);
+  gemm_epilogue<bf16_t, TC, 2>(acc, gl, Cp, g.vec_ok && bm + BM <= gl.M && bn + 64 <= g.N, bm + wid * 32, bn, lane);
 }
 
 template <typename TC>
@@ -1240,17 +1264,24 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (prc != PG_OK) return prc;
   dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->batch);
   hipStream_t st = (hipStream_t)stream;
+  if (d->seq_off) {  // ragged batches: the 128x64-tile kernel only (checked in gemm_prepare)
+    ProfEntry* pe = prof_begin(8 + (d->c_dtype == PG_F32 ? 4 : 0) + (d->a_kmajor ? 2 : 0) + (d->b_kmajor ? 1 : 0),
+                               2.0 * d->M * d->N * (d->K2 > 0 ? 2.0 : 1.0) * d->K * d->batch, st);
+    const int rc = d->c_dtype == PG_F32 ? launch_glds_n64<float>(d, a, st) : launch_glds_n64<bf16_t>(d, a, st);
+    if (pe) hipEventRecord(pe->b, st);
+    return rc;
+  }
   const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && d->K2 % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
                     (d->b_kmajor || d->N >= 8);
   const long blocks128 = (long)grid.x * grid.y * grid.z;
-  const bool narrow = fast && d->K2 == 0 && ((g_gemm_narrow >= 1 && d->N <= 64) || (g_gemm_narrow == 2 && blocks128 <= 256) ||
-                              (g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
+  const bool narrow = fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (d->K2 == 0 && g_gemm_narrow == 2 && blocks128 <= 256) ||
+                              (d->K2 == 0 && g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
                      // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round down to
                      // 160 tiles (192 tiles on 256 CUs beat 768 tiles of 128x128 by 17 %; at 128 tiles they lose)
                      (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= g_gemm_wide_min_tiles));
-  if (d->K2 > 0 && (!fast || narrow || !g_gemm_dualk)) {
+  if (d->K2 > 0 && (!fast || !g_gemm_dualk || (d->batch != 1 && !narrow))) {
     // only the 128x128 and 256x256 direct-to-LDS kernels walk two reduction segments: elsewhere two launches
     if (d->bias || d->residual || d->act != PG_ACT_NONE) return PG_ERR_UNSUPPORTED;  // the epilogue would apply twice
     pg_gemm_desc one = *d;
@@ -1353,8 +1384,15 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
   a.act = d->act;
   a.A2 = nullptr; a.B2 = nullptr; a.K2 = 0;
   a.group_m = g_gemm_group_m;
+  a.seq_off = d->seq_off; a.seq_tok0 = d->seq_tok0; a.seq_ops = d->seq_ops;
+  if (d->seq_off) {
+    // sequence zo of every (zo, zi) batch has its own M = K <= the descriptor's: whole 64-row tiles of a
+    // score-shaped operand are walked (zeros past the extent), token-row operands are clamped
+    if (d->dtype != PG_BF16 || d->N > 64 || d->N % 8 || d->M != d->K || d->seq_tok0 < 0 || (d->seq_ops & ~7)) return PG_ERR_UNSUPPORTED;
+    if (d->b_kmajor || d->bias || d->residual || d->aux) return PG_ERR_UNSUPPORTED;
+  }
   if (d->K2 > 0) {
-    if (!d->A2 || !d->B2 || d->batch != 1) return PG_ERR_ARG;
+    if (!d->A2 || !d->B2 || (d->batch != 1 && d->N > 64)) return PG_ERR_ARG;
     if (((uintptr_t)d->A2 | (uintptr_t)d->B2) & 15) return PG_ERR_ALIGN;
     if (d->a_kmajor && d->lda < ((d->K2 + epc - 1) / epc) * epc) return PG_ERR_ARG;
     if (d->b_kmajor && d->ldb < ((d->K2 + epc - 1) / epc) * epc) return PG_ERR_ARG;

@@ -317,15 +317,17 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 // ------------------------------------------------------------------ gradient-penalty reductions
 template <typename T>
 __global__ __launch_bounds__(256) void gp_sumsq_kernel(const T* __restrict__ g, const float* __restrict__ mask, int S, int H,
-                                                        float* __restrict__ sumsq) {
+                                                        float* __restrict__ sumsq, const int* __restrict__ seq_off) {
   const int b = blockIdx.y;
-  const long per = (long)S * H;
+  // sample b: S rows from row b*S, or (ragged) the rows [seq_off[b], seq_off[b+1])
+  const long first = seq_off ? seq_off[b] : (long)b * S;
+  const long per = (seq_off ? (long)(seq_off[b + 1] - seq_off[b]) : (long)S) * H;
   const long n4 = per / 4;
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float v[4];
-    VecIO<T, 4>::load(g + b * per + i * 4, v);
-    const float m = mask ? mask[(long)b * S + (i * 4) / H] : 1.f;
+    VecIO<T, 4>::load(g + first * H + i * 4, v);
+    const float m = mask ? mask[first + (i * 4) / H] : 1.f;
     s += m * m * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
   }
   __shared__ float red[4];
@@ -349,20 +351,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void gp_direction_kernel(const T* __restrict__ g, const float* __restrict__ mask,
                                                             const float* __restrict__ norms, int B, int S, int H,
                                                             const float* __restrict__ scale_dev, T* __restrict__ v,
-                                                            float* __restrict__ gp_out) {
+                                                            float* __restrict__ gp_out, const int* __restrict__ seq_off) {
   const int b = blockIdx.y;
-  const long per = (long)S * H;
+  const long first = seq_off ? seq_off[b] : (long)b * S;
+  const long per = (seq_off ? (long)(seq_off[b + 1] - seq_off[b]) : (long)S) * H;
   const long n4 = per / 4;
   const float n = norms[b];
   const float scale = scale_dev ? *scale_dev : 1.0f;
   const float coef = n > 0.f ? scale * (2.0f / (float)B) * (n - 1.0f) / n : 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float x[4];
-    VecIO<T, 4>::load(g + b * per + i * 4, x);
-    const float m = mask ? mask[(long)b * S + (i * 4) / H] : 1.f;
+    VecIO<T, 4>::load(g + first * H + i * 4, x);
+    const float m = mask ? mask[first + (i * 4) / H] : 1.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] *= coef * m;
-    VecIO<T, 4>::store(v + b * per + i * 4, x);
+    VecIO<T, 4>::store(v + first * H + i * 4, x);
   }
   if (gp_out && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
@@ -395,19 +398,60 @@ __global__ __launch_bounds__(256) void interp_kernel(const T* __restrict__ a, co
   }
 }
 
+// Ragged interpolation: token row t of x belongs to sequence b = seq_id[t] and is its row j = t - off_x[b];
+// the real and fake embeddings of that sequence start at rows off_r[b] and off_f[b] of er / ef (each batch
+// packed to its own lengths, every one at least the interpolates' length).  One wave per row.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void interp_ragged_kernel(const T* __restrict__ a, const T* __restrict__ bsrc,
+                                                             const float* __restrict__ alpha, T* __restrict__ o1,
+                                                             T* __restrict__ o2, const int* __restrict__ seq_id,
+                                                             const int* __restrict__ off_x, const int* __restrict__ off_r,
+                                                             const int* __restrict__ off_f, int Tn, int H, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= Tn) return;
+  const int b = seq_id[t];
+  const long j = t - off_x[b];
+  const long rr = (long)off_r[b] + j, rf = (long)off_f[b] + j;
+  const float al = alpha[b];
+  for (int c = lane * 4; c < H; c += 256) {
+    float x[4], y[4];
+    if (!BWD) {
+      VecIO<T, 4>::load(a + rr * H + c, x);
+      VecIO<T, 4>::load(bsrc + rf * H + c, y);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = al * x[e] + (1.0f - al) * y[e];
+      VecIO<T, 4>::store(o1 + t * H + c, x);
+    } else {
+      VecIO<T, 4>::load(a + t * H + c, x);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = (1.0f - al) * x[e]; x[e] = al * x[e]; }
+      if (accumulate) {
+        float p[4], q[4];
+        VecIO<T, 4>::load(o1 + rr * H + c, p);
+        VecIO<T, 4>::load(o2 + rf * H + c, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] += p[e]; y[e] += q[e]; }
+      }
+      VecIO<T, 4>::store(o1 + rr * H + c, x);
+      VecIO<T, 4>::store(o2 + rf * H + c, y);
+    }
+  }
+}
+
 // Scatter of the embedding-sum gradient into the word and position tables (fp32 atomics);
 // the token-type row receives the column sum through pg_colsum_acc.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ dsum, const int64_t* __restrict__ ids,
                                                              float* __restrict__ gword, float* __restrict__ gpos, int S,
-                                                             int H, long n_tokens) {
+                                                             int H, long n_tokens, const int* __restrict__ pos_ids) {
   const long total = n_tokens * H;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long t = e / H;
     const int c = (int)(e % H);
     const float v = to_f32<T>(dsum[e]);
     if (gword) atomicAdd(gword + ids[t] * H + c, v);
-    if (gpos) atomicAdd(gpos + (t % S) * H + c, v);
+    if (gpos) atomicAdd(gpos + (pos_ids ? (long)pos_ids[t] : t % S) * H + c, v);
   }
 }
 
@@ -552,8 +596,8 @@ extern "C" int pg_head_jvp_grad(int dtype, const float* head, float* stash, cons
   return check_launch();
 }
 
-extern "C" int pg_gp_norms(int dtype, const void* g, const float* mask, int B, int S, int H, float* norms, float* gp_out,
-                           void* stream) {
+static int gp_norms_launch(int dtype, const void* g, const float* mask, const int32_t* seq_off, int B, int S, int H,
+                           float* norms, float* gp_out, void* stream) {
   if (!g || !norms || B <= 0 || S <= 0 || (H % 4)) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(norms, 0, sizeof(float) * B, st) != hipSuccess) return PG_ERR_LAUNCH;
@@ -562,15 +606,24 @@ extern "C" int pg_gp_norms(int dtype, const void* g, const float* mask, int B, i
   if (bx > 256) bx = 256;
   dim3 grid(bx, B);
   if (dtype == PG_F32)
-    hipLaunchKernelGGL(gp_sumsq_kernel<float>, grid, dim3(256), 0, st, (const float*)g, mask, S, H, norms);
+    hipLaunchKernelGGL(gp_sumsq_kernel<float>, grid, dim3(256), 0, st, (const float*)g, mask, S, H, norms, seq_off);
   else
-    hipLaunchKernelGGL(gp_sumsq_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, mask, S, H, norms);
+    hipLaunchKernelGGL(gp_sumsq_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, mask, S, H, norms, seq_off);
   hipLaunchKernelGGL(gp_sqrt_kernel, dim3(1), dim3(64), 0, st, norms, B, gp_out);
   return check_launch();
 }
+extern "C" int pg_gp_norms(int dtype, const void* g, const float* mask, int B, int S, int H, float* norms, float* gp_out,
+                           void* stream) {
+  return gp_norms_launch(dtype, g, mask, nullptr, B, S, H, norms, gp_out, stream);
+}
+extern "C" int pg_gp_norms_ragged(int dtype, const void* g, const float* mask, const int32_t* seq_off, int B, int max_len,
+                                  int H, float* norms, float* gp_out, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return gp_norms_launch(dtype, g, mask, seq_off, B, max_len, H, norms, gp_out, stream);
+}
 
-extern "C" int pg_gp_direction(int dtype, const void* g, const float* mask, const float* norms, int B, int S, int H,
-                               const float* scale_dev, void* v, float* gp_out, void* stream) {
+static int gp_direction_launch(int dtype, const void* g, const float* mask, const float* norms, const int32_t* seq_off, int B,
+                               int S, int H, const float* scale_dev, void* v, float* gp_out, void* stream) {
   if (!g || !norms || !v || B <= 0 || S <= 0 || (H % 4)) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long n4 = (long)S * H / 4;
@@ -579,10 +632,48 @@ extern "C" int pg_gp_direction(int dtype, const void* g, const float* mask, cons
   dim3 grid(bx, B);
   if (dtype == PG_F32)
     hipLaunchKernelGGL(gp_direction_kernel<float>, grid, dim3(256), 0, st, (const float*)g, mask, norms, B, S, H,
-                       scale_dev, (float*)v, gp_out);
+                       scale_dev, (float*)v, gp_out, seq_off);
   else
     hipLaunchKernelGGL(gp_direction_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, mask, norms, B, S, H,
-                       scale_dev, (bf16_t*)v, gp_out);
+                       scale_dev, (bf16_t*)v, gp_out, seq_off);
+  return check_launch();
+}
+extern "C" int pg_gp_direction(int dtype, const void* g, const float* mask, const float* norms, int B, int S, int H,
+                               const float* scale_dev, void* v, float* gp_out, void* stream) {
+  return gp_direction_launch(dtype, g, mask, norms, nullptr, B, S, H, scale_dev, v, gp_out, stream);
+}
+extern "C" int pg_gp_direction_ragged(int dtype, const void* g, const float* mask, const float* norms, const int32_t* seq_off,
+                                      int B, int max_len, int H, const float* scale_dev, void* v, float* gp_out, void* stream) {
+  if (!seq_off) return PG_ERR_ARG;
+  return gp_direction_launch(dtype, g, mask, norms, seq_off, B, max_len, H, scale_dev, v, gp_out, stream);
+}
+
+extern "C" int pg_interpolate_ragged(int dtype, const void* er, const void* ef, const float* alpha, void* x,
+                                     const int32_t* seq_id, const int32_t* off_x, const int32_t* off_r, const int32_t* off_f,
+                                     int T, int H, void* stream) {
+  if (!er || !ef || !alpha || !x || !seq_id || !off_x || !off_r || !off_f || T <= 0 || H <= 0 || (H & 3)) return PG_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 3) / 4);
+  if (dtype == PG_F32)
+    hipLaunchKernelGGL((interp_ragged_kernel<float, false>), grid, dim3(256), 0, st, (const float*)er, (const float*)ef, alpha,
+                       (float*)x, (float*)nullptr, seq_id, off_x, off_r, off_f, T, H, 0);
+  else
+    hipLaunchKernelGGL((interp_ragged_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)er, (const bf16_t*)ef,
+                       alpha, (bf16_t*)x, (bf16_t*)nullptr, seq_id, off_x, off_r, off_f, T, H, 0);
+  return check_launch();
+}
+extern "C" int pg_interpolate_bwd_ragged(int dtype, const void* dx, const float* alpha, void* der, void* def,
+                                         const int32_t* seq_id, const int32_t* off_x, const int32_t* off_r,
+                                         const int32_t* off_f, int T, int H, int accumulate, void* stream) {
+  if (!dx || !alpha || !der || !def || !seq_id || !off_x || !off_r || !off_f || T <= 0 || H <= 0 || (H & 3)) return PG_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((T + 3) / 4);
+  if (dtype == PG_F32)
+    hipLaunchKernelGGL((interp_ragged_kernel<float, true>), grid, dim3(256), 0, st, (const float*)dx, (const float*)nullptr,
+                       alpha, (float*)der, (float*)def, seq_id, off_x, off_r, off_f, T, H, accumulate);
+  else
+    hipLaunchKernelGGL((interp_ragged_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)dx, (const bf16_t*)nullptr,
+                       alpha, (bf16_t*)der, (bf16_t*)def, seq_id, off_x, off_r, off_f, T, H, accumulate);
   return check_launch();
 }
 
@@ -619,22 +710,31 @@ extern "C" int pg_interpolate_bwd(int dtype, const void* dx, const float* alpha,
   return check_launch();
 }
 
-extern "C" int pg_embed_scatter(int dtype, const void* dsum, const int64_t* ids, float* gword, float* gpos, float* gtype0,
-                                int B, int S, int H, void* stream) {
+static int embed_scatter_launch(int dtype, const void* dsum, const int64_t* ids, const int32_t* pos_ids, float* gword,
+                                float* gpos, float* gtype0, int B, int S, int H, void* stream) {
   if (!dsum || !ids || B <= 0 || S <= 0 || H <= 0) return PG_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long n_tokens = (long)B * S;
   if (gword || gpos) {
     if (dtype == PG_F32)
       hipLaunchKernelGGL(embed_scatter_kernel<float>, dim3(ew_blocks(n_tokens * H)), dim3(256), 0, st, (const float*)dsum,
-                         ids, gword, gpos, S, H, n_tokens);
+                         ids, gword, gpos, S, H, n_tokens, pos_ids);
     else
       hipLaunchKernelGGL(embed_scatter_kernel<bf16_t>, dim3(ew_blocks(n_tokens * H)), dim3(256), 0, st, (const bf16_t*)dsum,
-                         ids, gword, gpos, S, H, n_tokens);
+                         ids, gword, gpos, S, H, n_tokens, pos_ids);
     if (hipGetLastError() != hipSuccess) return PG_ERR_LAUNCH;
   }
   if (gtype0) return pg_colsum_acc(dtype, dsum, H, (int)n_tokens, H, gtype0, stream);
   return PG_OK;
+}
+extern "C" int pg_embed_scatter(int dtype, const void* dsum, const int64_t* ids, float* gword, float* gpos, float* gtype0,
+                                int B, int S, int H, void* stream) {
+  return embed_scatter_launch(dtype, dsum, ids, nullptr, gword, gpos, gtype0, B, S, H, stream);
+}
+extern "C" int pg_embed_scatter_packed(int dtype, const void* dsum, const int64_t* ids, const int32_t* pos_ids, float* gword,
+                                       float* gpos, float* gtype0, int T, int H, void* stream) {
+  if (!pos_ids) return PG_ERR_ARG;
+  return embed_scatter_launch(dtype, dsum, ids, pos_ids, gword, gpos, gtype0, 1, T, H, stream);
 }
 
 extern "C" int pg_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,

@@ -521,6 +521,12 @@ extern "C" int pg_embed_ln_packed(int dtype, const int64_t* ids, const int32_t* 
   if (!pos_ids) return PG_ERR_ARG;
   return embed_ln_launch(dtype, ids, pos_ids, word, pos, type0, gamma, beta, eps, out, nullptr, 1, T, H, stream);
 }
+extern "C" int pg_embed_ln2_packed(int dtype, const int64_t* ids, const int32_t* pos_ids, const float* word, const float* pos,
+                                   const float* type0, const float* gamma, const float* beta, float eps, void* out,
+                                   void* sum_out, int T, int H, void* stream) {
+  if (!pos_ids) return PG_ERR_ARG;
+  return embed_ln_launch(dtype, ids, pos_ids, word, pos, type0, gamma, beta, eps, out, sum_out, 1, T, H, stream);
+}
 extern "C" int pg_embed_ln(int dtype, const int64_t* ids, const float* word, const float* pos, const float* type0,
                            const float* gamma, const float* beta, float eps, void* out, int B, int S, int H, void* stream) {
   return pg_embed_ln2(dtype, ids, word, pos, type0, gamma, beta, eps, out, nullptr, B, S, H, stream);

@@ -22,12 +22,15 @@ from . import ops
 from ._lib import check, lib
 from .loss import compute_gradient_penalty, critic_loss, generator_loss
 from .models import Critic, Generator, RowPacking
+from .ragged import Ragged, extents, plan_lengths
 
 
 # A/B switch (PG_ONE_FORWARD=0 restores the call-by-call critic update everywhere)
 ONE_FORWARD_DEFAULT = os.environ.get("PG_ONE_FORWARD", "1") != "0"
 # with one forward: also one first-order backward over the 3B sequences (PG_ONE_BACKWARD=0: two, B and 2B)
 ONE_BACKWARD_DEFAULT = os.environ.get("PG_ONE_BACKWARD", "1") != "0"
+# with one forward: every row runs on its own leading columns up to the last one its mask shows (PG_RAGGED=0: all S)
+RAGGED_DEFAULT = os.environ.get("PG_RAGGED", "1") != "0"
 
 
 @dataclass
@@ -214,7 +217,7 @@ def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequ
 
 
 def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask_real, fake, fake_mask, hp: GanHyper,
-                               grad_sync, alpha) -> torch.Tensor:
+                               grad_sync, alpha, ragged=False, real_lengths=None, fake_lengths=None) -> torch.Tensor:
     """The critic update with ONE encoder forward over 3B sequences: the gradient-penalty interpolates
     (loss.py:22-66) and the real and fake rows (fully_masked_train.py:321-323) use the same weights, and at
     B = 8 a forward over 4096 or 8192 token rows runs at little more than half the rate of one over 12 288.
@@ -235,6 +238,16 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     alpha = alpha.to(device=dev, dtype=torch.float32).contiguous().view(B)
     rmask = attn_mask_real.to(dev)
     joint = (rmask.bool() & fake_mask.bool()).to(torch.float32)
+    if ragged and ONE_BACKWARD_DEFAULT and S % 8 == 0:
+        # columns each row needs: up to the last one its mask shows (bounds given by the caller, or read back)
+        er = [min(S, int(v)) for v in real_lengths] if real_lengths is not None else extents(rmask)
+        ef = [min(S, int(v)) for v in fake_lengths] if fake_lengths is not None else extents(fake_mask)
+        lens_j = plan_lengths([min(a, b) for a, b in zip(er, ef)], S)
+        lens_rf = plan_lengths(er + ef, S, floor=lens_j + lens_j)
+        if sum(lens_j) + sum(lens_rf) < 3 * B * S:
+            return _critic_update_ragged(critic, critic_optimizer, real, rmask.to(torch.float32), fake,
+                                         fake_mask.to(torch.float32), joint, lens_j, lens_rf[:B], lens_rf[B:], hp, grad_sync,
+                                         alpha)
     mask3 = torch.cat([joint, rmask.to(torch.float32), fake_mask.to(torch.float32)], dim=0).contiguous()
 
     # embeddings of both batches straight into their rows of the 3B input, interpolates into the first B
@@ -312,16 +325,103 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     return c_loss.detach()
 
 
+def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, fake_mask, joint, lens_j, lens_r, lens_f,
+                          hp: GanHyper, grad_sync, alpha) -> torch.Tensor:
+    """_critic_update_one_forward over ragged rows: sequence b of the interpolates, of the real and of the fake
+    batch runs on its lens_j[b] / lens_r[b] / lens_f[b] leading columns (lens_j[b] <= both others), all 3B
+    sequences laid back to back.  Columns left out are hidden by the masks in every pass of the reference
+    (loss.py:41-66, models.py:87-93) and get zero gradient there; here they are not computed."""
+    m, head = critic.protbert, critic.classifier
+    B, S = real.shape
+    H = m.config.hidden_size
+    cd = m.compute_dtype
+    dt = ops.dt_code(cd)
+    st = ops.stream()
+    dev = real.device
+    lam = float(hp.lambda_gp)
+    rg3 = Ragged(list(lens_j) + list(lens_r) + list(lens_f), S, dev)
+    rgJ = Ragged(lens_j, S, dev)
+    rgRF = Ragged(list(lens_r) + list(lens_f), S, dev)
+    Tj, Trf, T3 = rgJ.T, rgRF.T, rg3.T
+    Tr = rgRF.off[B]
+    off_r = rgRF.seq_off[:B]
+    off_f = rgRF.seq_off[B:2 * B]  # (rows of the fake batch inside the real+fake buffers: offsets from their start)
+    mask3 = torch.cat([rgJ.pack(joint), rgRF.pack(torch.cat([rmask, fake_mask], dim=0))]).contiguous()
+    ids_rf = rgRF.pack(torch.cat([real, fake], dim=0)).contiguous()
+
+    # embeddings of the real and fake rows straight into their rows of the input, interpolates in front
+    X = torch.empty(T3, H, dtype=cd, device=dev)
+    sums = torch.empty(Trf, H, dtype=cd, device=dev)
+    m._embed_packed(ids_rf, rgRF.pos, X[Tj:], sums)
+    check(lib.pg_interpolate_ragged(dt, X[Tj:].data_ptr(), X[Tj:].data_ptr(), alpha.data_ptr(), X.data_ptr(),
+                                    rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H, st),
+          "pg_interpolate_ragged")
+    hidden, stash = m._encode_ragged(rg3, x=X, mask_p=mask3, want_stash=True)
+    del X
+    cls = hidden.index_select(0, rg3.cls_rows)  # [3B, H]: the rows the critic reads (models.py:104)
+    scores = torch.empty(3 * B, 1, dtype=torch.float32, device=dev)
+    hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
+    check(lib.pg_head_forward(dt, cls.data_ptr(), H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
+                              hstash.data_ptr(), st), "pg_head_forward")
+    m.store.begin_accumulate()
+    head.store.begin_accumulate()
+    ghead = head.store.grad
+    w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
+    norms = torch.empty(B, dtype=torch.float32, device=dev)
+    gp = torch.empty((), dtype=torch.float32, device=dev)
+    # one first-order backward over the 3B sequences (see _critic_update_one_forward)
+    dcls = torch.empty(3 * B, H, dtype=cd, device=dev)
+    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dcls.data_ptr(), H, st),
+          "pg_head_backward")
+    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                               ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
+    dh3 = torch.zeros(T3, H, dtype=cd, device=dev).index_copy_(0, rg3.cls_rows, dcls)
+    adj = m._new_stash(3 * B, S, T3)
+    dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B, rgd=rg3.desc(), T=T3)
+    g, dx2 = dx3[:Tj], dx3[Tj:]
+    check(lib.pg_gp_norms_ragged(dt, g.data_ptr(), mask3.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H, norms.data_ptr(),
+                                 gp.data_ptr(), st), "pg_gp_norms_ragged")
+    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
+    # penalty direction, tangent pass, second-order pass (loss.py's create_graph backward) on the first B sequences
+    scale = torch.full((), lam, dtype=torch.float32, device=dev)
+    v = torch.empty_like(g)
+    check(lib.pg_gp_direction_ragged(dt, g.data_ptr(), mask3.data_ptr(), norms.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H,
+                                     scale.data_ptr(), v.data_ptr(), None, st), "pg_gp_direction_ragged")
+    tan = m._new_stash(B, S, Tj)
+    rgd = rg3.desc(0, B, stash_T=T3, adj_T=T3)
+    hdot = m._encode_jvp(stash, v, B, S, tan, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
+    hdot_cls = hdot.index_select(0, rgJ.cls_rows)
+    tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
+    check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot_cls.data_ptr(), H, B, H, 1.0,
+                               ghead.data_ptr(), tstash.data_ptr(), None, st), "pg_head_jvp_grad")
+    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0, adj_rows=3 * B, rgd=rgd, T=Tj)
+    # the interpolates' input gradient joins the real and fake rows' own (loss.py:29), then one embedding backward
+    check(lib.pg_interpolate_bwd_ragged(dt, xbar.data_ptr(), alpha.data_ptr(), dx2.data_ptr(), dx2.data_ptr(),
+                                        rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H,
+                                        1, st), "pg_interpolate_bwd_ragged")
+    m._embed_backward_packed(ids_rf, rgRF.pos, sums, dx2)
+    if grad_sync is not None:
+        grad_sync()
+    critic_optimizer.step()
+    return c_loss.detach()
+
+
 def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, fake_data, hp: GanHyper,
                   pad_id=0, grad_sync: Optional[Callable[[], None]] = None, alpha=None,
-                  one_forward: Optional[bool] = None) -> torch.Tensor:
+                  one_forward: Optional[bool] = None, real_lengths=None, fake_lengths=None,
+                  ragged: Optional[bool] = None) -> torch.Tensor:
     """fully_masked_train.py:297-326 / 10p_train.py:327-338.  `grad_sync` (data-parallel
     gradient averaging) runs between backward and the optimizer step.  Returns c_loss
     (device scalar; the caller decides when to synchronise for logging).
 
     `one_forward` (default: whenever every critic parameter trains): interpolates, real and fake rows
     share one encoder forward, see _critic_update_one_forward; False = the reference's sequence of calls
-    through autograd."""
+    through autograd.
+
+    `ragged` (default on, with one_forward): every row runs on its leading columns up to the last one its mask
+    shows, see _critic_update_ragged.  `real_lengths` / `fake_lengths`: per row, an upper bound of that column
+    count known on the host (the tokenizer's lengths, the fake templates' lengths); without them the masks are
+    read back once (one device-to-host copy per update)."""
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
     trainable = critic.protbert.encoder_trainable() and critic.classifier[0].weight.requires_grad
@@ -334,7 +434,10 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
         fk = critic.protbert._check_ids(fake)
         if real.shape != fk.shape:
             raise ValueError(f"real {tuple(real.shape)} and fake {tuple(fk.shape)} batches differ in shape")
-        return _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha)
+        if ragged is None:
+            ragged = RAGGED_DEFAULT
+        return _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha,
+                                          ragged, real_lengths, fake_lengths)
     critic_optimizer.zero_grad()
     gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device, alpha=alpha)
     # real and fake rows go through the encoder as one 2B-row batch (rows are independent, so the
@@ -394,9 +497,10 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     temps.append(fill_temperatures(hp))
     fakes = generate_fake_batches(generator, lengths, temps, hp, device)
     c_sum = None
-    for batch, fake, alpha in zip(real_batches, fakes, alphas):
+    for batch, fake, alpha, fl in zip(real_batches, fakes, alphas, lengths):
+        # (a fake row's non-pad columns end inside its template: positions past it are never masks, so never filled)
         c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
-                          grad_sync=grad_sync, alpha=alpha)
+                          grad_sync=grad_sync, alpha=alpha, real_lengths=batch.get("lengths"), fake_lengths=fl)
         c_sum = c if c_sum is None else c_sum + c
     g = generator_update(critic, gen_optimizer, fakes[-1])
     return c_sum / hp.n_critic, g
@@ -411,9 +515,10 @@ def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_
     c_sum = None
     if stacked_generation:
         fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:hp.n_critic + 1]], hp)
-        for batch, fake in zip(real_batches[:hp.n_critic], fakes):
+        for batch, fake, gb in zip(real_batches[:hp.n_critic], fakes, gen_batches):
+            # (a seeded fake keeps the pad columns of the sequence it started from)
             c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
-                              grad_sync=grad_sync)
+                              grad_sync=grad_sync, real_lengths=batch.get("lengths"), fake_lengths=gb.get("lengths"))
             c_sum = c if c_sum is None else c_sum + c
         g = generator_update(critic, gen_optimizer, fakes[hp.n_critic])
         return c_sum / hp.n_critic, g
@@ -434,10 +539,13 @@ def synthetic_real_batch(batch_size: int, length_pool: Sequence[int], max_len: i
     which is not distributed with the reference."""
     ids = torch.zeros(batch_size, max_len, dtype=torch.long)
     mask = torch.zeros(batch_size, max_len, dtype=torch.float32)
+    lengths = []
     for b in range(batch_size):
         L = min(rng.choice(length_pool), max_len - 2)
         ids[b, 0] = 2
         ids[b, 1:L + 1] = torch.randint(5, 25, (L,), generator=gen)
         ids[b, L + 1] = 3
         mask[b, :L + 2] = 1.0
-    return {"input_ids": ids.to(device), "attention_mask": mask.to(device)}
+        lengths.append(L + 2)
+    # "lengths": what a tokenizer knows on the host (tokens per row before padding, dataset.py:19-25)
+    return {"input_ids": ids.to(device), "attention_mask": mask.to(device), "lengths": lengths}
