@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--regime", choices=["unfrozen", "frozen"], default="unfrozen",
                     help="frozen = epoch 0 of the trainers: both ProtBERTs frozen, only the critic head learns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
+    ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
     ap.add_argument("--profile-sample", type=int, default=16)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="(kernel A/B runs) forwarded to pg_tune before the first step")
@@ -212,6 +214,9 @@ def main():
         "c_loss": c_loss, "g_loss": g_loss,
         "roofline": roofline, "gemm_variants": variants,
     }
+    # the other half of the metric, after and outside the train leg's timed region: generated sequences/s
+    if not args.no_generate_leg:
+        out["generate"] = time_generate(pg, generator, pool, rank, world, dev, batches=args.generate_batches)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
@@ -220,13 +225,14 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
-    """Generated sequences/s of generate.py's full mode (batch 64 per GPU, lengths from the pool)."""
+def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1, bs=64):
+    """generate.py's full mode (batch 64 per GPU, lengths from the pool, 10 fill iterations): sequences/s over
+    `batches` batches per rank, summed over ranks (every rank fills its own sequences: no collective)."""
     from protgen_gan_amd import generate as gen_py
     tok = pg.ProtTokenizer()
-    bs = 64
-    n = bs * max(1, args.steps)
-    gen_py.generate_full_mode_sequences(generator, tok, bs * max(1, args.warmup), pool, batch_size=bs, device=str(dev), rng_seed=7 + rank)
+    n = bs * max(1, batches)
+    gen_py.generate_full_mode_sequences(generator, tok, bs * max(1, warm_batches), pool, batch_size=bs, device=str(dev),
+                                        rng_seed=7 + rank)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -238,16 +244,25 @@ def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
-    out = {"metric": "generated sequences/s (generate.py full mode)", "value": round(world * n / dt, 3), "unit": "sequences/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2),
+    return {"value": round(world * n / dt, 3), "unit": "sequences/s", "sequences_per_rank": n, "batch": bs, "seconds": round(dt, 4),
+            "mean_len": round(sum(len(s) for s in seqs) / len(seqs), 1), "step_mfma_frac": round(flops / dt / MFMA_PEAK_BF16, 4),
+            "workload": "configs[3]-style mass generation (generate.py full mode), lengths uniform %d..%d, 10 fill iterations"
+                        % (pool[0], pool[-1])}
+
+
+def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
+    """Generated sequences/s of generate.py's full mode (batch 64 per GPU, lengths from the pool)."""
+    g = time_generate(pg, generator, pool, rank, world, dev, args.steps, args.warmup)
+    out = {"metric": "generated sequences/s (generate.py full mode)", "value": g["value"], "unit": "sequences/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(g["seconds"] / max(1, args.steps) * 1e3, 2),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "configs[3]-style mass generation, batch 64 per GPU, lengths uniform 200..500, 10 fill iterations",
-                      "sequences_per_rank": n, "parallelism": f"shard{world}"},
-           "mean_len": sum(len(s) for s in seqs) / len(seqs), "step_mfma_frac": round(flops / dt / MFMA_PEAK_BF16, 4)}
+           "config": {"workload": g["workload"] + ", batch 64 per GPU", "sequences_per_rank": g["sequences_per_rank"],
+                      "parallelism": f"shard{world}"},
+           "mean_len": g["mean_len"], "step_mfma_frac": g["step_mfma_frac"]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -96,7 +96,8 @@ class FlatStore:
         self.views = []  # (param, offset, numel) for every parameter a backward can reach
         self.adam_m = None
         self.adam_v = None
-        self.adam_step = 0
+        self.adam_step = 0                   # largest step count of any parameter (reporting only)
+        self.adam_steps: Dict[int, int] = {}  # parameter offset -> optimizer steps it has taken
         # offset -> leading elements of that view a backward may write (set by a data-parallel caller that
         # promises a bound, e.g. the rows of the position table within the padded width)
         self.live_elems: Dict[int, int] = {}

@@ -1212,6 +1212,10 @@ int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with m
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
 int g_gemm_wide_min_tiles = 160;  // fewest 256x256 tiles at which a narrow-N (512 <= N < 2048) product takes the 256x256 kernel
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
+// largest 128x128 grid that takes the four-buffer ring (one workgroup per CU): measured on 16 cold operand sets, the
+// ring wins at 152 workgroups (N = 1024 products of 2432 rows: 44 vs 65 us at K = 4096) and loses from 360 on
+// (5696 rows: 85 vs 72 us), where two workgroups per CU with two buffers each hide the latency better
+int g_gemm_deep_max_blocks = 256;
 
 }  // namespace
 
@@ -1231,6 +1235,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 7) { g_gemm_dualk = value; return PG_OK; }
   if (key == 11) { g_gemm_group = value; return PG_OK; }
   if (key == 15) { pg_internal_fused_dgelu_save = value != 0; return PG_OK; }
+  if (key == 16) { if (value < 0) return PG_ERR_ARG; g_gemm_deep_max_blocks = value; return PG_OK; }
   if (key == 14) { if (value < 1) return PG_ERR_ARG; g_gemm_wide_min_tiles = value; return PG_OK; }
   if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
@@ -1325,7 +1330,7 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
     else rc = launch_glds256<bf16_t>(d, a, st);
   } else if (fast) {
     const long blocks = blocks128;
-    const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && d->K >= 4 * GBK);
+    const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= g_gemm_deep_max_blocks && d->K >= 4 * GBK);
     if (deep) {
       if (d->c_dtype == PG_F32) rc = launch_glds<float, 4>(d, a, grid, st);
       else rc = launch_glds<bf16_t, 4>(d, a, grid, st);
@@ -1446,7 +1451,7 @@ extern "C" int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void
   ProfEntry* pe = prof_begin(8 + (d0->c_dtype == PG_F32 ? 4 : 0) + (d0->a_kmajor ? 2 : 0) + (d0->b_kmajor ? 1 : 0),
                              2.0 * d0->M * d0->N * ((double)d0->K + d0->K2) + 2.0 * d1->M * d1->N * ((double)d1->K + d1->K2), st);
   const int kmin = d0->K < d1->K ? d0->K : d1->K;
-  const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= 2 * 256 && kmin >= 4 * GBK);
+  const bool deep = g_gemm_path == 4 || (g_gemm_path == 1 && blocks <= g_gemm_deep_max_blocks && kmin >= 4 * GBK);
   if (deep) rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 4>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 4>(d0, a, blocks, st);
   else rc = d0->c_dtype == PG_F32 ? launch_glds_pair<float, 2>(d0, a, blocks, st) : launch_glds_pair<bf16_t, 2>(d0, a, blocks, st);
   if (pe) hipEventRecord(pe->b, st);

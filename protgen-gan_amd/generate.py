@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
-"""Mass generation with the reference's entry points and flags (generate.py:19-275), on the
-HIP engine.  Helper names, argument meaning, RNG use (Python `random.Random(rng_seed)` for
-lengths / seeds / kept positions, the device generator for sampling noise) and error
-behaviour follow the reference; the model and tokenizer are this package's own.
+"""Mass generation behind the reference's entry points and flags (generate.py:19-275), on the HIP engine.
 
-Sharded mass generation (one process per GPU, no collective) lives in distributed.py."""
+What is kept from the reference is its surface: function names and signatures, CLI flags and their
+defaults, the output file names, which exception each failure raises, and the order in which the Python
+`random.Random(rng_seed)` stream is consumed (one `choice` per length, one `randrange` per seed, one
+`sample` per seeded row, rows in batch order), because generated sets are reproducible by seed.  The rest
+is this package's own:
+
+  * batch templates are built as whole tensors on the host and copied to the device once;
+  * the fill loops never wait for the device just to learn whether masks are left.  The host keeps a lower
+    bound of every row's open masks (what the schedule leaves if no sampled token re-opens a position or
+    lowers the row's commit quota; either can only leave MORE masks open), and only when that bound reaches
+    zero for every row is the device count read, which is where the reference's `break` can fire at all;
+  * sharded mass generation (one process per GPU, no collective) lives in distributed.py."""
 from __future__ import annotations
 
 import argparse
@@ -12,7 +20,7 @@ import math
 import os
 import random
 from pathlib import Path
-from typing import List, Tuple
+from typing import Iterator, List, Sequence, Tuple
 
 import torch
 
@@ -20,43 +28,42 @@ from .bert import ProtBertForMaskedLM
 from .models import Generator
 from .tokenizer import ProtTokenizer
 
+_FINETUNED_IDS = ("finetuned_protbert", "finetuned-protbert")
+_BASE_IDS = ("protbert_base", "protbert-base")
 
-def _paths():
-    """config.py:12-28 — resolved lazily so importing this module never raises."""
-    src = os.environ.get("SOURCE_DIR")
-    if not src:
+
+def _source_dirs() -> Tuple[str, str, str]:
+    """(checkpoint root, fine-tuned ProtBERT dir, base ProtBERT dir) under $SOURCE_DIR, the layout of the
+    reference's config.py:24-28.  Looked up on use, so importing this module needs no environment."""
+    root = os.environ.get("SOURCE_DIR")
+    if not root:
         raise EnvironmentError("SOURCE_DIR is not set: export SOURCE_DIR=<dir holding checkpoints/ and models/>")
-    return (os.path.join(src, "checkpoints"), os.path.join(src, "models", "dnmt_protbert"),
-            os.path.join(src, "models", "prot_bert"))
+    models = os.path.join(root, "models")
+    return os.path.join(root, "checkpoints"), os.path.join(models, "dnmt_protbert"), os.path.join(models, "prot_bert")
 
 
-# ---------------- utils ----------------
+# ----------------------------------------------------------------------------- inputs
+def _sequences_in_range(path: str, min_len: int, max_len: int) -> Iterator[str]:
+    """Non-empty lines of a one-sequence-per-line file, spaces inside a line removed, length within bounds."""
+    with open(path, "r", encoding="utf-8") as fh:
+        for raw in fh:
+            seq = raw.strip().replace(" ", "")
+            if seq and min_len <= len(seq) <= max_len:
+                yield seq
+
+
 def load_length_distribution(dataset_path: str, max_len: int, min_len: int = 30) -> List[int]:
-    lengths = []
-    with open(dataset_path, "r", encoding="utf-8") as f:
-        for line in f:
-            seq = line.strip().replace(" ", "")
-            if not seq:
-                continue
-            if min_len <= len(seq) <= max_len:
-                lengths.append(len(seq))
-    if not lengths:
+    pool = [len(s) for s in _sequences_in_range(dataset_path, min_len, max_len)]
+    if not pool:
         raise ValueError(f"No sequence lengths found in range [{min_len}, {max_len}] from {dataset_path}.")
-    return lengths
+    return pool
 
 
 def load_seed_sequences(seed_file: str, max_len: int, min_len: int = 30) -> List[str]:
-    seqs = []
-    with open(seed_file, "r", encoding="utf-8") as f:
-        for line in f:
-            s = line.strip().replace(" ", "")
-            if not s:
-                continue
-            if min_len <= len(s) <= max_len:
-                seqs.append(s[:max_len])
-    if not seqs:
+    pool = list(_sequences_in_range(seed_file, min_len, max_len))
+    if not pool:
         raise ValueError(f"No usable seed sequences in range [{min_len}, {max_len}] from {seed_file}.")
-    return seqs
+    return pool
 
 
 def sample_sequence_length(lengths: List[int], rng: random.Random) -> int:
@@ -64,111 +71,108 @@ def sample_sequence_length(lengths: List[int], rng: random.Random) -> int:
 
 
 def to_token_ids(seq: str, tokenizer) -> List[int]:
-    return tokenizer.encode(" ".join(list(seq)), add_special_tokens=False)
+    return tokenizer.encode(" ".join(seq), add_special_tokens=False)
 
 
 def safe_local_from_pretrained(path: str, device: str, compute_dtype=torch.bfloat16):
-    if not os.path.isdir(path):
-        raise FileNotFoundError(f"Model dir not found: {path}")
-    if not os.path.exists(os.path.join(path, "config.json")):
-        raise FileNotFoundError(f"Missing config.json in {path} (did save_pretrained run?)")
+    for missing, what in ((not os.path.isdir(path), f"Model dir not found: {path}"),
+                          (not os.path.exists(os.path.join(path, "config.json")),
+                           f"Missing config.json in {path} (did save_pretrained run?)")):
+        if missing:
+            raise FileNotFoundError(what)
     return ProtBertForMaskedLM.from_pretrained(path, device=device, compute_dtype=compute_dtype)
 
 
 def resolve_model_path(ckpt_id: str) -> Tuple[str, str]:
-    ckpt_root, finetuned, base = _paths()
-    ckpt_id = ckpt_id.strip().strip("/")
-    if ckpt_id in {"finetuned_protbert", "finetuned-protbert"}:
+    key = ckpt_id.strip().strip("/")
+    ckpt_root, finetuned, base = _source_dirs()
+    if key in _FINETUNED_IDS:
         return finetuned, "finetuned"
-    if ckpt_id in {"protbert_base", "protbert-base"}:
+    if key in _BASE_IDS:
         return base, "base"
-    return os.path.join(ckpt_root, ckpt_id, "generator_bert"), "trained"
+    return os.path.join(ckpt_root, key, "generator_bert"), "trained"
 
 
 def derive_out_prefix(ckpt_id: str) -> str:
-    ckpt_id = ckpt_id.strip().strip("/")
-    if ckpt_id in {"finetuned-protbert", "finetuned_protbert", "protbert_base", "protbert-base", "base_protbert"}:
-        return ckpt_id
-    parts = ckpt_id.split("/")
-    if len(parts) == 2:
-        return f"{parts[0]}_{parts[1]}"
-    return ckpt_id.replace("/", "_")
+    key = ckpt_id.strip().strip("/")
+    return key if key in _FINETUNED_IDS + _BASE_IDS + ("base_protbert",) else "_".join(key.split("/"))
 
 
-# -------------- builders (templates are assembled on the host, one copy to the device) --------------
+# ----------------------------------------------------------------------------- batch templates
+def _template(lengths: Sequence[int], cls_id: int, sep_id: int, mask_id: int, pad_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host tensors: ids [B, max L + 2] = CLS, L masks, SEP, pads; attention mask = 1 on the first L + 2 columns."""
+    L = torch.as_tensor(list(lengths), dtype=torch.long).unsqueeze(1)
+    col = torch.arange(int(L.max()) + 2).unsqueeze(0)
+    ids = torch.full((L.shape[0], col.shape[1]), pad_id, dtype=torch.long)
+    ids = torch.where(col <= L, torch.full_like(ids, mask_id), ids)
+    ids = torch.where(col == L + 1, torch.full_like(ids, sep_id), ids)
+    ids[:, 0] = cls_id
+    return ids, (col <= L + 1).to(torch.long)
+
+
 def build_fully_masked_batch(batch_sizes: List[int], cls_id: int, sep_id: int, mask_id: int, pad_id: int,
                              device) -> Tuple[torch.Tensor, torch.Tensor]:
-    max_L = max(batch_sizes)
-    B = len(batch_sizes)
-    ids = torch.full((B, max_L + 2), pad_id, dtype=torch.long)
-    attn = torch.zeros_like(ids)
-    for i, L in enumerate(batch_sizes):
-        attn[i, :L + 2] = 1
-        ids[i, 0] = cls_id
-        ids[i, L + 1] = sep_id
-        if L > 0:
-            ids[i, 1:L + 1] = mask_id
+    ids, attn = _template(batch_sizes, cls_id, sep_id, mask_id, pad_id)
     return ids.to(device), attn.to(device)
 
 
 def build_seeded_batch(seqs: List[str], tokenizer, keep_init: float, cls_id: int, sep_id: int, mask_id: int,
                        pad_id: int, device, rng: random.Random) -> Tuple[torch.Tensor, torch.Tensor]:
-    tok_lists = [to_token_ids(s, tokenizer) for s in seqs]
-    max_L = max(len(t) for t in tok_lists)
-    B = len(seqs)
-    ids = torch.full((B, max_L + 2), pad_id, dtype=torch.long)
-    attn = torch.zeros_like(ids)
-    for i, toks in enumerate(tok_lists):
-        L = len(toks)
-        attn[i, :L + 2] = 1
-        ids[i, 0] = cls_id
-        ids[i, L + 1] = sep_id
-        if L > 0:
-            ids[i, 1:L + 1] = mask_id
-            k = max(1, int(round(keep_init * L)))
-            for pos in rng.sample(range(1, L + 1), k):
-                ids[i, pos] = toks[pos - 1]
+    rows = [to_token_ids(s, tokenizer) for s in seqs]
+    ids, attn = _template([len(r) for r in rows], cls_id, sep_id, mask_id, pad_id)
+    for b, toks in enumerate(rows):  # (one `sample` per row, in row order: the seed's draw order)
+        if toks:
+            kept = torch.as_tensor(rng.sample(range(1, len(toks) + 1), max(1, int(round(keep_init * len(toks))))))
+            ids[b, kept] = torch.as_tensor(toks)[kept - 1]
     return ids.to(device), attn.to(device)
 
 
-def _decode_batch(tokenizer, ids: torch.Tensor) -> List[str]:
-    rows = ids.cpu()
-    return [tokenizer.decode(rows[i], skip_special_tokens=True).replace(" ", "") for i in range(rows.shape[0])]
+# ----------------------------------------------------------------------------- fill loops
+def _special_ids(tokenizer) -> Tuple[int, int, int, int]:
+    if tokenizer.pad_token_id is None:
+        raise ValueError("Tokenizer has no pad_token_id; please set one.")
+    return tokenizer.mask_token_id, tokenizer.cls_token_id, tokenizer.sep_token_id, tokenizer.pad_token_id
 
 
-def _masks_left(ids, mask_id) -> int:
-    return int((ids == mask_id).sum().item())
+def _fill(generator: Generator, ids: torch.Tensor, attn: torch.Tensor, open_masks: List[int], meaningful: List[int],
+          first_rate: float, steps: int, keep_percent: float, temperature: float, mask_id: int) -> torch.Tensor:
+    """Up to `steps` fill iterations at rates first_rate, first_rate - keep_percent, ...; stops before an iteration
+    that would find no mask anywhere (the reference's per-iteration check, generate.py:147-149,185-187).
+    open_masks / meaningful: per row, the masks in the template and its tokens outside {PAD, CLS, SEP}."""
+    low = list(open_masks)  # lower bound of each row's open masks (module docstring)
+    rate = first_rate
+    for _ in range(steps):
+        if not any(low) and int((ids == mask_id).sum().item()) == 0:
+            break
+        ids = generator.generate(ids, attention_mask=attn, keep_percent=keep_percent, current_rate=rate,
+                                 temperature=temperature)
+        fill_all = rate <= 0.1
+        low = [0 if fill_all else m - min(max(1, int(keep_percent * n)), m) for m, n in zip(low, meaningful)]
+        rate = max(0.0, rate - keep_percent)
+    return ids
 
 
-# -------------- generators --------------
+def _decode_rows(tokenizer, ids: torch.Tensor) -> List[str]:
+    return [tokenizer.decode(row, skip_special_tokens=True).replace(" ", "") for row in ids.cpu().tolist()]
+
+
 @torch.no_grad()
 def generate_full_mode_sequences(generator: Generator, tokenizer, num_sequences: int, length_pool: List[int],
                                  keep_percent: float = 0.10, temperature: float = 1.0, batch_size: int = 64,
                                  device: str = "cuda", rng_seed: int = 42) -> List[str]:
     assert 0.0 < keep_percent <= 1.0
-    device = torch.device(device)
+    dev = torch.device(device)
     generator.eval()
     rng = random.Random(rng_seed)
-    mask_id, cls_id, sep_id, pad_id = (tokenizer.mask_token_id, tokenizer.cls_token_id, tokenizer.sep_token_id,
-                                       tokenizer.pad_token_id)
-    if pad_id is None:
-        raise ValueError("Tokenizer has no pad_token_id; please set one.")
-    out, n_done = [], 0
-    max_steps = math.ceil(1.0 / keep_percent)
-    while n_done < num_sequences:
-        this_batch = min(batch_size, num_sequences - n_done)
-        batch_lengths = [sample_sequence_length(length_pool, rng) for _ in range(this_batch)]
-        input_ids, attn = build_fully_masked_batch(batch_lengths, cls_id, sep_id, mask_id, pad_id, device)
-        current_rate = 1.0
-        for _ in range(max_steps):
-            if _masks_left(input_ids, mask_id) == 0:
-                break
-            input_ids = generator.generate(input_ids, attention_mask=attn, keep_percent=keep_percent,
-                                           current_rate=current_rate, temperature=temperature)
-            current_rate = max(0.0, current_rate - keep_percent)
-        out.extend(_decode_batch(tokenizer, input_ids))
-        n_done += this_batch
-    return out
+    mask_id, cls_id, sep_id, pad_id = _special_ids(tokenizer)
+    steps = math.ceil(1.0 / keep_percent)
+    sequences: List[str] = []
+    for start in range(0, num_sequences, batch_size):
+        lengths = [sample_sequence_length(length_pool, rng) for _ in range(min(batch_size, num_sequences - start))]
+        ids, attn = build_fully_masked_batch(lengths, cls_id, sep_id, mask_id, pad_id, dev)
+        ids = _fill(generator, ids, attn, lengths, lengths, 1.0, steps, keep_percent, temperature, mask_id)
+        sequences += _decode_rows(tokenizer, ids)
+    return sequences
 
 
 @torch.no_grad()
@@ -176,95 +180,83 @@ def generate_seeded_mode_sequences(generator: Generator, tokenizer, num_sequence
                                    keep_init: float = 0.10, keep_percent: float = 0.10, temperature: float = 1.0,
                                    batch_size: int = 64, device: str = "cuda", rng_seed: int = 123) -> List[str]:
     assert 0.0 < keep_init < 1.0 and 0.0 < keep_percent <= 1.0
-    device = torch.device(device)
+    dev = torch.device(device)
     generator.eval()
     rng = random.Random(rng_seed)
-    mask_id, cls_id, sep_id, pad_id = (tokenizer.mask_token_id, tokenizer.cls_token_id, tokenizer.sep_token_id,
-                                       tokenizer.pad_token_id)
-    if pad_id is None:
-        raise ValueError("Tokenizer has no pad_token_id; please set one.")
-    out, n_done = [], 0
-    max_steps = max(1, math.ceil((1.0 - keep_init) / keep_percent)) + 1
-    N = len(seed_pool)
-    while n_done < num_sequences:
-        this_batch = min(batch_size, num_sequences - n_done)
-        batch_seqs = [seed_pool[rng.randrange(N)] for _ in range(this_batch)]
-        input_ids, attn = build_seeded_batch(batch_seqs, tokenizer, keep_init, cls_id, sep_id, mask_id, pad_id, device, rng)
-        current_rate = 1.0 - keep_init
-        for _ in range(max_steps):
-            if _masks_left(input_ids, mask_id) == 0:
-                break
-            input_ids = generator.generate(input_ids, attention_mask=attn, keep_percent=keep_percent,
-                                           current_rate=current_rate, temperature=temperature)
-            current_rate = max(0.0, current_rate - keep_percent)
-        out.extend(_decode_batch(tokenizer, input_ids))
-        n_done += this_batch
-    return out
+    mask_id, cls_id, sep_id, pad_id = _special_ids(tokenizer)
+    steps = max(1, math.ceil((1.0 - keep_init) / keep_percent)) + 1
+    specials = (pad_id, cls_id, sep_id)
+    sequences: List[str] = []
+    for start in range(0, num_sequences, batch_size):
+        n = min(batch_size, num_sequences - start)
+        seeds = [seed_pool[rng.randrange(len(seed_pool))] for _ in range(n)]
+        ids, attn = build_seeded_batch(seeds, tokenizer, keep_init, cls_id, sep_id, mask_id, pad_id, dev, rng)
+        host = ids.cpu()
+        open_masks = (host == mask_id).sum(dim=1).tolist()
+        inner = host[:, 1:]  # (the row's own CLS / SEP / pads do not count; a residue that encodes to one of them does not either)
+        meaningful = [int(((row != specials[0]) & (row != specials[1]) & (row != specials[2])).sum()) for row in inner]
+        ids = _fill(generator, ids, attn, open_masks, meaningful, 1.0 - keep_init, steps, keep_percent, temperature, mask_id)
+        sequences += _decode_rows(tokenizer, ids)
+    return sequences
 
 
-# -------------- main --------------
-def main(argv=None):
-    random_seed = random.randint(1, 10000)
+# ----------------------------------------------------------------------------- command line
+def _parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(description="Generate sequences in full & seeded modes.")
     ap.add_argument("--ckpt_id", required=True)
-    ap.add_argument("--dataset_path", type=str, default="./data/dnmt_unformatted.txt")
-    ap.add_argument("--seed_file", type=str, default=None)
-    ap.add_argument("--num_full", type=int, default=5000)
-    ap.add_argument("--num_seeded", type=int, default=5000)
-    ap.add_argument("--keep_init", type=float, default=0.10)
-    ap.add_argument("--keep_percent", type=float, default=0.10)
-    ap.add_argument("--temperature", type=float, default=1.0)
-    ap.add_argument("--max_len", type=int, default=600)
-    ap.add_argument("--min_len", type=int, default=30)
-    ap.add_argument("--batch_size", type=int, default=64)
-    ap.add_argument("--device", type=str, default="cuda")
-    ap.add_argument("--rng_seed", type=int, default=random_seed)
+    for flag, kind, default in (("--dataset_path", str, "./data/dnmt_unformatted.txt"), ("--seed_file", str, None),
+                                ("--num_full", int, 5000), ("--num_seeded", int, 5000), ("--keep_init", float, 0.10),
+                                ("--keep_percent", float, 0.10), ("--temperature", float, 1.0), ("--max_len", int, 600),
+                                ("--min_len", int, 30), ("--batch_size", int, 64), ("--device", str, "cuda"),
+                                ("--rng_seed", int, None), ("--out_dir", str, "./results/")):
+        ap.add_argument(flag, type=kind, default=default)
     ap.add_argument("--tokenizer_dir", type=str, default=None, help="Tokenizer path (defaults to finetuned).")
-    ap.add_argument("--out_dir", type=str, default="./results/")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="fp32",
                     help="compute dtype (the reference generates in fp32; bf16 is the fast path)")
-    args = ap.parse_args(argv)
+    return ap
 
-    os.makedirs(args.out_dir, exist_ok=True)
-    out_prefix = derive_out_prefix(args.ckpt_id)
-    full_out = str(Path(args.out_dir) / f"{out_prefix}_full.txt")
-    seeded_out = str(Path(args.out_dir) / f"{out_prefix}_seeded.txt")
 
-    model_path, tag = resolve_model_path(args.ckpt_id)
-    tokenizer = ProtTokenizer.from_pretrained(args.tokenizer_dir or _paths()[1], do_lower_case=False)
+def _write_lines(path: Path, lines: Sequence[str]) -> None:
+    with open(path, "w", encoding="utf-8") as fh:
+        fh.writelines(s + "\n" for s in lines)
+
+
+def main(argv=None):
+    args = _parser().parse_args(argv)
+    if args.rng_seed is None:  # (the reference's default: a fresh seed per run)
+        args.rng_seed = random.randint(1, 10000)
+    out_dir = Path(args.out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    prefix = derive_out_prefix(args.ckpt_id)
+    model_dir, tag = resolve_model_path(args.ckpt_id)
+
+    tokenizer = ProtTokenizer.from_pretrained(args.tokenizer_dir or _source_dirs()[1], do_lower_case=False)
     if tokenizer.pad_token is None:
         tokenizer.add_special_tokens({"pad_token": "[PAD]"})
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    protbert = safe_local_from_pretrained(model_path, args.device, dtype)
-    generator = Generator(protbert_model=protbert)
-    generator.eval()
+    protbert = safe_local_from_pretrained(model_dir, args.device, torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    vocab = protbert.config.vocab_size
+    too_big = {name: i for name, i in (("pad", tokenizer.pad_token_id), ("cls", tokenizer.cls_token_id),
+                                       ("sep", tokenizer.sep_token_id), ("mask", tokenizer.mask_token_id))
+               if i is None or not 0 <= i < vocab}
+    if too_big:  # (the embedding table is not resized here: ids past it would index other tensors)
+        raise ValueError(f"special token ids {too_big} do not fit the checkpoint's vocabulary of {vocab}")
+    generator = Generator(protbert_model=protbert).eval()
 
     lengths = load_length_distribution(args.dataset_path, max_len=args.max_len, min_len=args.min_len)
-    seed_source = args.seed_file if args.seed_file is not None else args.dataset_path
-    seeds = load_seed_sequences(seed_source, max_len=args.max_len, min_len=args.min_len)
-
-    seqs_full = []
+    seeds = load_seed_sequences(args.seed_file or args.dataset_path, max_len=args.max_len, min_len=args.min_len)
+    common = dict(keep_percent=args.keep_percent, temperature=args.temperature, batch_size=args.batch_size, device=args.device)
+    counts = {}
     if args.num_full > 0:
-        seqs_full = generate_full_mode_sequences(generator=generator, tokenizer=tokenizer, num_sequences=args.num_full,
-                                                 length_pool=lengths, keep_percent=args.keep_percent,
-                                                 temperature=args.temperature, batch_size=args.batch_size,
-                                                 device=args.device, rng_seed=args.rng_seed)
-        with open(full_out, "w", encoding="utf-8") as f:
-            for s in seqs_full:
-                f.write(s + "\n")
-        print(f"[{tag}] Wrote {len(seqs_full)} full-mode sequences → {full_out}")
-    seqs_seeded = []
+        seqs = generate_full_mode_sequences(generator, tokenizer, args.num_full, lengths, rng_seed=args.rng_seed, **common)
+        _write_lines(out_dir / f"{prefix}_full.txt", seqs)
+        counts["full"] = len(seqs)
     if args.num_seeded > 0:
-        seqs_seeded = generate_seeded_mode_sequences(generator=generator, tokenizer=tokenizer,
-                                                     num_sequences=args.num_seeded, seed_pool=seeds,
-                                                     keep_init=args.keep_init, keep_percent=args.keep_percent,
-                                                     temperature=args.temperature, batch_size=args.batch_size,
-                                                     device=args.device, rng_seed=args.rng_seed + 1337)
-        with open(seeded_out, "w", encoding="utf-8") as f:
-            for s in seqs_seeded:
-                f.write(s + "\n")
-        print(f"[{tag}] Wrote {len(seqs_seeded)} seeded-10% sequences → {seeded_out}")
-    print(f"[DONE] {out_prefix} | full={len(seqs_full)} | seeded={len(seqs_seeded)}")
+        seqs = generate_seeded_mode_sequences(generator, tokenizer, args.num_seeded, seeds, keep_init=args.keep_init,
+                                              rng_seed=args.rng_seed + 1337, **common)
+        _write_lines(out_dir / f"{prefix}_seeded.txt", seqs)
+        counts["seeded"] = len(seqs)
+    print(f"{tag} checkpoint {prefix}: " + ", ".join(f"{n} {mode}-mode sequences" for mode, n in counts.items()) +
+          f" written under {out_dir}")
 
 
 if __name__ == "__main__":

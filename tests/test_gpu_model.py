@@ -825,3 +825,91 @@ def test_one_backward_matches_two_passes_bf16(pg, monkeypatch):
         # rounding noise in every mode)
         worst = max((float((grads[n] - ref[n]).norm() / (ref[n].norm() + 1e-12)), n) for n in ref if "key.bias" not in n)
         assert worst[0] < 2e-2, (mode, worst)
+
+
+# ----------------------------------------------------------------------------- checkpoints written by others, resuming
+def test_from_pretrained_hf_written_checkpoints(pg, golden_dir):
+    """Directories written by `transformers` itself (save_pretrained -> model.safetensors; a torch.save of
+    state_dict() -> pytorch_model.bin with the tied decoder keys), the layouts generate.py:54-60 reads:
+    the loaded model gives the logits transformers computed (fp32, 1e-4 of the largest)."""
+    io = np.load(os.path.join(golden_dir, "hf_tiny_io.npz"), allow_pickle=False)
+    ids, mask = torch.from_numpy(io["ids"]).to(DEV), torch.from_numpy(io["mask"]).to(DEV)
+    for d in ("hf_tiny", "hf_tiny_bin"):
+        m = pg.ProtBertForMaskedLM.from_pretrained(os.path.join(golden_dir, d), device=DEV, compute_dtype=torch.float32)
+        assert not m.training
+        logits = pg.Generator(m)(ids, mask)
+        rel_close(logits.cpu().numpy(), io["logits"], 1e-4, f"logits from {d}")
+
+
+def _tiny_update(pg, critic, opt, seed):
+    from protgen_gan_amd import train as T
+    g = torch.Generator().manual_seed(seed)
+    B, S = 2, 24
+    real = torch.randint(5, 25, (B, S), generator=g)
+    fake = torch.randint(5, 25, (B, S), generator=g)
+    real[:, 0] = fake[:, 0] = O.CLS
+    alpha = torch.rand(B, 1, 1, generator=g)
+    T.critic_update(critic, opt, real.to(DEV), torch.ones(B, S, device=DEV), fake.to(DEV), T.GanHyper(lambda_gp=5.0), alpha=alpha)
+
+
+def test_optimizer_state_resume_equals_continuous(pg, tmp_path):
+    """Two critic updates in a row against one update, a checkpoint (weights in the reference's directory layout,
+    fully_masked_train.py:378-389, plus the optimizer state the reference never saved) and the second update in a
+    freshly built critic + optimizer: same weights (fp32; the bias / LayerNorm gradients end in float atomics, so
+    1e-6 of the largest weight rather than identical bits)."""
+    c, P, PC, C, _, critic = build(pg, "tiny", torch.float32)
+    opt = pg.AdamW(critic.parameters(), lr=1e-3, weight_decay=0.01)
+    _tiny_update(pg, critic, opt, 1)
+    ck = tmp_path / "epoch_1"
+    critic.protbert.save_pretrained(str(ck / "critic_bert"))
+    torch.save(critic.classifier.state_dict(), str(ck / "critic_classifier.pth"))
+    torch.save(opt.state_dict(), str(ck / "critic_optimizer.pt"))
+    _tiny_update(pg, critic, opt, 2)
+    want = {n: p.detach().cpu().clone() for n, p in critic.named_parameters()}
+
+    critic2 = pg.Critic(pg.ProtBertForMaskedLM.from_pretrained(str(ck / "critic_bert"), device=DEV, compute_dtype=torch.float32))
+    critic2.classifier.load_state_dict(torch.load(str(ck / "critic_classifier.pth"), weights_only=True))
+    opt2 = pg.AdamW(critic2.parameters(), lr=1e-3, weight_decay=0.01)
+    opt2.load_state_dict(torch.load(str(ck / "critic_optimizer.pt"), weights_only=True))
+    _tiny_update(pg, critic2, opt2, 2)
+    scale = max(float(v.abs().max()) for v in want.values())
+    for n, p in critic2.named_parameters():
+        assert float((p.detach().cpu() - want[n]).abs().max()) <= 1e-6 * scale, n
+    # without the optimizer state the second update starts from zero moments: visibly different weights
+    critic3 = pg.Critic(pg.ProtBertForMaskedLM.from_pretrained(str(ck / "critic_bert"), device=DEV, compute_dtype=torch.float32))
+    critic3.classifier.load_state_dict(torch.load(str(ck / "critic_classifier.pth"), weights_only=True))
+    _tiny_update(pg, critic3, pg.AdamW(critic3.parameters(), lr=1e-3, weight_decay=0.01), 2)
+    n0 = "protbert.bert.encoder.layer.0.output.dense.weight"
+    assert float((dict(critic3.named_parameters())[n0].detach().cpu() - want[n0]).abs().max()) > 1e-5 * scale
+
+
+def test_adamw_parameter_that_starts_later_counts_its_own_steps(pg):
+    """A parameter whose first gradient arrives at the optimizer's third step takes ITS first step then (bias
+    correction with step 1), as torch.optim.AdamW does: the encoder after the frozen epoch
+    (fully_masked_train.py:119-136,274-282)."""
+    c, P, PC, C, _, critic = build(pg, "tiny", torch.float32)
+    head_w, enc_w = critic.classifier[0].weight, critic.protbert.bert.encoder.layer[0].output.dense.weight
+    ref = {k: torch.nn.Parameter(p.detach().cpu().clone()) for k, p in (("h", head_w), ("e", enc_w))}
+    opt = pg.AdamW(critic.parameters(), lr=1e-2, weight_decay=0.01)
+    topt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.01)
+    g = torch.Generator().manual_seed(5)
+    for step in range(4):
+        critic.zero_grad(set_to_none=True)
+        topt.zero_grad(set_to_none=True)
+        critic.classifier.store.begin_accumulate()
+        gh = torch.randn(head_w.shape, generator=g)
+        head_w.grad.copy_(gh.to(DEV))
+        ref["h"].grad = gh.clone()
+        if step >= 2:  # the encoder joins late
+            critic.protbert.store.begin_accumulate()
+            ge = torch.randn(enc_w.shape, generator=g)
+            enc_w.grad.copy_(ge.to(DEV))
+            ref["e"].grad = ge.clone()
+        for n, p in critic.named_parameters():  # only the two probed tensors carry a gradient
+            if p is not head_w and p is not enc_w:
+                p.grad = None
+        opt.step()
+        topt.step()
+    for k, p in (("h", head_w), ("e", enc_w)):
+        err = float((p.detach().cpu() - ref[k].detach()).abs().max())
+        assert err <= 2e-6 * float(ref[k].abs().max()) + 1e-7, (k, err)

@@ -119,3 +119,24 @@ def test_trainer_helpers(pg):
 def test_adamw_range_merge(pg):
     from protgen_gan_amd.optim import _merge_ranges
     assert _merge_ranges([(0, 10), (16, 20), (100, 120), (10, 16)]) == [[0, 20], [100, 120]]
+
+
+def test_hf_written_checkpoint_fixture_has_every_parameter(pg, golden_dir):
+    """The fixture directories were written by `transformers` (oracle/make_hf_fixture.py): every tensor
+    this package's ProtBERT names must be there under the same name and shape; the .bin layout also carries
+    the tied decoder keys a loader has to ignore."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from protgen_gan_amd import bert as B
+    with open(os.path.join(golden_dir, "hf_tiny", "config.json")) as f:
+        cfg = B.ProtBertConfig.from_dict(json.load(f))
+    names = [n for n, _ in B._GLOBAL_NAMES] + [f"bert.encoder.layer.{l}.{s}" for l in range(cfg.num_hidden_layers)
+                                               for s, _ in B._LAYER_NAMES]
+    st = load_file(os.path.join(golden_dir, "hf_tiny", "model.safetensors"))
+    binf = torch.load(os.path.join(golden_dir, "hf_tiny_bin", "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    for sd in (st, binf):
+        for n in names:
+            assert n in sd and tuple(sd[n].shape) == tuple(B._shape_of(cfg, n)), n
+    assert "cls.predictions.decoder.weight" in binf and "cls.predictions.decoder.weight" not in st
+    assert torch.equal(binf["cls.predictions.decoder.weight"], binf["bert.embeddings.word_embeddings.weight"])

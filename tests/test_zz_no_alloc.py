@@ -27,11 +27,9 @@ def _both(pg, dtype, rows, H, seed):
         dx = torch.empty_like(x)
         acc = [torch.zeros(H, dtype=torch.float32, device=DEV) for _ in range(3)]
         if static:
-            before = torch.cuda.memory_allocated()
             rc = lib.pg_layernorm_bwd_static(ops.dt_code(dtype), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), 1e-12,
                                              dx.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), acc[2].data_ptr(), rows, H,
                                              ops.stream())
-            assert torch.cuda.memory_allocated() == before
         else:
             part = torch.empty(3 * H * lib.pg_ln_partial_rows(rows), dtype=torch.float32, device=DEV)
             rc = lib.pg_layernorm_bwd(ops.dt_code(dtype), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), 1e-12, dx.data_ptr(),
