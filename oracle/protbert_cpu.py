@@ -457,3 +457,51 @@ def generate_seeded_mode_sequences(P, cfg, tok, num_sequences, seed_pool, keep_i
             out.append(tok.decode(ids[i], skip_special_tokens=True).replace(" ", ""))
         n_done += nb
     return out
+
+
+# ----------------------------------------------------------------------------- the trainers' fake-batch loops
+# (10p_train.py and fully_masked_train.py cannot be imported: they parse arguments, load models and data at
+# module level.  The two loops below restate their fake-batch functions by reading; every arithmetic piece
+# they call, generate_step above, is pinned by the reference's own outputs.  The compositions are not.)
+def trainer_fakes_seeded(P, cfg, input_ids, random_mask, temperatures, noises, initial_mask_rate=0.9, iteration_rate=0.1,
+                         unk_id=1):
+    """10p_train.py:132-184.  random_mask: the boolean draw `torch.rand(shape) < rate` (:142); temperatures: one per
+    fill iteration (:158); noises: one Exp(1) draw [B*S, V] per iteration.  Returns (ids, iterations run)."""
+    meaningful = (input_ids != PAD) & (input_ids != unk_id) & (input_ids != CLS) & (input_ids != SEP)
+    ids = input_ids.clone()
+    ids[meaningful & random_mask] = MASK
+    rate, it = initial_mask_rate, 0
+    while rate > 0:
+        attn = (ids != PAD).long()                       # :153-156
+        with torch.no_grad():
+            ids = generate_step(P, cfg, ids, attn, temperatures[it], iteration_rate, rate, noises[it])
+        it += 1
+        rate = max(0, rate - iteration_rate)
+        if int((ids == MASK).sum()) == 0:                # :179-182
+            break
+    return ids, it
+
+
+def trainer_fakes_blind(P, cfg, lengths, temperatures, noises, max_len, initial_mask_rate=0.9, iteration_rate=0.1):
+    """fully_masked_train.py:195-258.  lengths: total lengths (sampled length + 2, :205); attention mask
+    `ids != MASK` recomputed every iteration (:222); the result is padded or cut to max_len (:252-256)."""
+    S = max(lengths)
+    ids = torch.full((len(lengths), S), PAD, dtype=torch.long)
+    for i, L in enumerate(lengths):
+        ids[i, :L] = MASK
+        ids[i, 0] = CLS
+        ids[i, L - 1] = SEP
+    rate, it = initial_mask_rate, 0
+    while rate > 0:
+        attn = (ids != MASK).long()
+        with torch.no_grad():
+            ids = generate_step(P, cfg, ids, attn, temperatures[it], iteration_rate, rate, noises[it])
+        it += 1
+        rate = max(0, rate - iteration_rate)
+        if int((ids == MASK).sum()) == 0:
+            break
+    if S < max_len:
+        ids = torch.nn.functional.pad(ids, (0, max_len - S), value=PAD)
+    elif S > max_len:
+        ids = ids[:, :max_len]
+    return ids, it

@@ -89,11 +89,13 @@ def generate_fake_batch(generator: Generator, batch_size_local: int, length_pool
 
 
 def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: GanHyper, mask_id=4, cls_id=2,
-                             sep_id=3, pad_id=0, unk_id=1) -> torch.Tensor:
+                             sep_id=3, pad_id=0, unk_id=1, random_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Seeded mode (10p_train.py:132-184): mask 90 % of the meaningful positions of real
-    sequences, attention mask `ids != PAD`, fill until no mask is left."""
+    sequences, attention mask `ids != PAD`, fill until no mask is left.  random_mask (tests): the boolean draw of
+    10p_train.py:142 instead of the device generator's."""
     meaningful = (input_ids != pad_id) & (input_ids != unk_id) & (input_ids != cls_id) & (input_ids != sep_id)
-    random_mask = torch.rand(input_ids.shape, device=input_ids.device) < hp.initial_masking_rate
+    if random_mask is None:
+        random_mask = torch.rand(input_ids.shape, device=input_ids.device) < hp.initial_masking_rate
     ids = input_ids.clone()
     ids[meaningful & random_mask] = mask_id
     rate = hp.initial_masking_rate
@@ -109,7 +111,8 @@ def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: 
 
 
 def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tensor], hp: GanHyper, mask_id=4, cls_id=2,
-                               sep_id=3, pad_id=0, unk_id=1, packed: bool = True) -> List[torch.Tensor]:
+                               sep_id=3, pad_id=0, unk_id=1, packed: bool = True,
+                               random_masks: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
     """Seeded-mode fakes for several real batches at once (the generator does not change between the
     critic updates of one iteration): every batch is masked as generate_fakes_for_batch masks it (its own
     device draw for the 90 % mask, its own CPU draw of a temperature per fill iteration, in batch order),
@@ -122,9 +125,10 @@ def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tens
     if any(x.size(1) != S for x in inputs):
         raise ValueError("seeded batches must share one padded width")
     parts, temps_per_batch, spans, r = [], [], [], 0
-    for x in inputs:
+    for bi, x in enumerate(inputs):
         meaningful = (x != pad_id) & (x != unk_id) & (x != cls_id) & (x != sep_id)
-        random_mask = torch.rand(x.shape, device=x.device) < hp.initial_masking_rate
+        random_mask = (random_masks[bi] if random_masks is not None
+                       else torch.rand(x.shape, device=x.device) < hp.initial_masking_rate)
         ids = x.clone()
         ids[meaningful & random_mask] = mask_id
         parts.append(ids)
@@ -530,6 +534,32 @@ def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_
     fake = generate_fakes_for_batch(generator, gen_batches[hp.n_critic]["input_ids"], hp)
     g = generator_update(critic, gen_optimizer, fake)
     return c_sum / hp.n_critic, g
+
+
+@torch.no_grad()
+def generate_eval_sequences(generator: Generator, tokenizer, num_sequences: int, length_pool: Sequence[int], device,
+                            rng=random, noise_fn=None) -> List[str]:
+    """The fill schedule of the in-training evaluation (val_metrics.py:96-140): one sequence at a time, a sampled
+    length, `[CLS] MASK.. [SEP]` under an all-ones attention mask, rates 1.0, 0.9, ... while above zero (eleven
+    iterations: the last one, at 1.4e-16, commits every mask left), temperature 1.0.  The reference also draws one
+    CPU uniform(0.8, 1.2) per iteration and never uses it; the draw is made here too, it moves the CPU generator.
+    noise_fn(n_rows, vocab) (tests): the Exp(1) draw of each iteration instead of the device generator's."""
+    mask_id, cls_id, sep_id = tokenizer.mask_token_id, tokenizer.cls_token_id, tokenizer.sep_token_id
+    out = []
+    for _ in range(num_sequences):
+        L = sample_sequence_length(length_pool, rng=rng)
+        ids = torch.full((1, L + 2), mask_id, dtype=torch.long)
+        ids[0, 0], ids[0, -1] = cls_id, sep_id
+        ids = ids.to(device)
+        attn = torch.ones_like(ids)
+        rate = 1.0
+        while rate > 0:
+            torch.empty(1).uniform_(0.8, 1.2)
+            noise = noise_fn(ids.numel(), generator.protbert.config.vocab_size) if noise_fn is not None else None
+            ids = generator.generate(ids, attn, keep_percent=0.1, current_rate=rate, temperature=1.0, noise=noise)
+            rate = max(0, rate - 0.1)
+        out.append(tokenizer.decode(ids[0].cpu(), skip_special_tokens=True).replace(" ", "")[:600])
+    return out
 
 
 def synthetic_real_batch(batch_size: int, length_pool: Sequence[int], max_len: int, device, rng: random.Random,

