@@ -107,10 +107,6 @@ typedef struct {
    * operands are score-shaped slots addressed by the batch strides; whole 64-row tiles of them are read, so
    * the rows / columns between a sequence's extent and the next multiple of 64 must hold zeros. */
   const int32_t* seq_off; int seq_tok0; int seq_ops;
-  /* Optional (unbatched, beta == 0): colsum[n] += sum over rows m >= colsum_row0 of the value written to C[m][n]
-   * (fp32 atomics).  torch's autograd sums a Linear's output gradient over the tokens into the bias gradient as
-   * a pass of its own; here the epilogue that produces that output gradient does it. */
-  float* colsum; int colsum_row0;
 } pg_gemm_desc;
 int pg_gemm(const pg_gemm_desc* d, void* stream);
 /* Two unbatched products in one launch (results identical to pg_gemm(d0) then pg_gemm(d1)):

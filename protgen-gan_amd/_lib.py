@@ -39,8 +39,7 @@ class GemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("aux", C.c_void_p), ("ldaux", C.c_int64), ("aux2", C.c_void_p), ("act", C.c_int),
                 ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int),
-                ("seq_off", C.c_void_p), ("seq_tok0", C.c_int), ("seq_ops", C.c_int),
-                ("colsum", C.c_void_p), ("colsum_row0", C.c_int)]
+                ("seq_off", C.c_void_p), ("seq_tok0", C.c_int), ("seq_ops", C.c_int)]
 
 
 class RaggedDesc(C.Structure):

@@ -474,14 +474,33 @@ class ProtBertForMaskedLM(nn.Module):
         return m.eval()
 
     # -- input normalisation
-    def _check_ids(self, ids):
+    def _guard_device(self):
+        """Kernels are launched on the current device's current stream: the model's device has to be that device."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            raise RuntimeError(f"model on {self.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                               f"call torch.cuda.set_device({self.device.index}) (or use `with torch.cuda.device(...)`)")
+
+    def _check_ids(self, ids, values=True):
+        """Shape, type and device of an id matrix; with `values`, also that every id is a row of the embedding table
+        (torch's embedding raises on such an id; the kernels here would read or add into a neighbouring table).
+        The value check reads two numbers back from the device; a tensor that passed is remembered by address,
+        shape and version, so a fill loop that hands the same buffer back every iteration pays once."""
         if ids.dim() != 2 or ids.dtype != torch.int64:
             raise TypeError("input_ids must be a [B,S] int64 tensor")
         if ids.device != self.device:
             raise ValueError(f"input_ids on {ids.device}, model on {self.device}")
+        self._guard_device()
         if ids.shape[1] > self.config.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
-        return ids.contiguous()
+        ids = ids.contiguous()
+        if values and ids.numel():
+            key = (ids.data_ptr(), tuple(ids.shape), ids._version)
+            if key != getattr(self, "_ids_checked", None):
+                lo, hi = (int(v) for v in torch.aminmax(ids))
+                if lo < 0 or hi >= self.config.vocab_size:
+                    raise IndexError(f"token id out of range: ids span [{lo}, {hi}], vocabulary has {self.config.vocab_size}")
+                self._ids_checked = key
+        return ids
 
     def _mask01(self, mask, B, S):
         if mask is None:

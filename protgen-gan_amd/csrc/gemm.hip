@@ -66,9 +66,6 @@ struct GemmArgs {
   // (bits of seq_ops: 1 = A, 2 = B, 4 = C) start at row seq_off[zo] - seq_tok0 of their buffers and M = K =
   // seq_off[zo+1] - seq_off[zo]; score-shaped operands keep their batch strides.
   const int* seq_off; int seq_tok0; int seq_ops;
-  // optional: colsum[n] += sum over the output rows m >= colsum_row0 of the value written to C[m][n] (before its
-  // rounding to the output type): the bias gradient of a Linear, taken where its output gradient is produced
-  float* colsum; int colsum_row0;
 };
 
 // ---- global -> register staging of one operand tile -------------------------------------
@@ -227,21 +224,6 @@ template <typename TC> __device__ __forceinline__ void store4(TC* p, const float
   }
 }
 
-// Column sums of a wave's share of the output: lane brings s[c], the sum over its own rows of column col[c]; the
-// sixteen lanes that differ only in lane & 15 hold different rows of the same columns.
-template <int NC>
-__device__ __forceinline__ void colsum_flush(const float (&s)[NC], const int (&col)[NC], float* dst, int N, int lane) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    float v = s[c];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    if ((lane & 15) == 0 && col[c] < N) atomicAdd(dst + col[c], v);
-  }
-}
-
 // ---- epilogue: lane owns C[m][n..n+3], m = ... + (lane&15), n = ... + 4*(lane>>4)
 // Interior tiles with vector-aligned operands take a branch-free path: the bias is fetched
 // once per column group as a float4, and the residual / auxiliary / accumulate loads of one
@@ -270,9 +252,6 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
   }
   const T* aux = reinterpret_cast<const T*>(g.aux);
   const T* res = reinterpret_cast<const T*>(g.residual);
-  float cs[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) cs[c] = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const long m = m0 + i * 16;
@@ -330,19 +309,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) VecIO<TC, 4>::store(Cp + m * g.ldc + n0 + (jh + j) * 16, v[j]);
-      if (g.colsum && m >= g.colsum_row0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cs[(jh + j) * 4 + e] += v[j][e];
-      }
     }
-  }
-  if (g.colsum) {
-    int col[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) col[c] = n0 + (c >> 2) * 16 + (c & 3);
-    colsum_flush<16>(cs, col, g.colsum, g.N, lane);
   }
 }
 
@@ -373,9 +340,6 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
       for (int e = 0; e < 8; ++e) bv[h][e] = 0.f;
     }
   }
-  float cs[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) cs[c] = 0.f;
   // Row block outermost: the two 64-byte halves of every 128-byte output line leave in consecutive
   // store instructions.  (Column group outermost put eight stores between them, and fabric-side
   // write bytes of a 4096-wide output measured 1.4x the output size: lines written back half full,
@@ -415,17 +379,7 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
         for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
       }
       VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
-      if (g.colsum && m >= g.colsum_row0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[h * 8 + e] += v[e];
-      }
     }
-  }
-  if (g.colsum) {
-    int col[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) col[c] = nn[c >> 3] + (c & 7);
-    colsum_flush<16>(cs, col, g.colsum, g.N, lane);
   }
 }
 
@@ -445,9 +399,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArg
     return;
   }
   const bool vec = g.vec_ok != 0;
-  float cs[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) cs[c] = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m_base + i * 16 + (lane & 15);
@@ -489,18 +440,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArg
         for (int e = 0; e < 4; ++e) v[e] += g.beta * c0[e];
       }
       store4<TC>(cp, v, v4, nvalid);
-      if (g.colsum && m >= g.colsum_row0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) cs[j * 4 + e] += v[e];
-      }
     }
-  }
-  if (g.colsum) {  // (every lane of the wave is here: rows and columns past the edge added nothing)
-    int col[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) col[c] = n_base + (c >> 2) * 16 + 4 * (lane >> 4) + (c & 3);
-    colsum_flush<16>(cs, col, g.colsum, g.N, lane);
   }
 }
 
@@ -1375,7 +1315,6 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
       if (d->aux) rest.aux = (char*)d->aux + rows1 * d->ldaux * esz;
       if (d->aux2) rest.aux2 = (char*)d->aux2 + rows1 * d->ldaux * esz;
       if (d->K2 > 0) rest.A2 = (const char*)d->A2 + rows1 * d->lda * esz;  // second segment: same rows of A2
-      if (d->colsum) rest.colsum_row0 = d->colsum_row0 > rows1 ? d->colsum_row0 - (int)rows1 : 0;
       const int rc1 = pg_gemm(&top, stream);
       return rc1 != PG_OK ? rc1 : pg_gemm(&rest, stream);
     }
@@ -1451,8 +1390,6 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
   a.A2 = nullptr; a.B2 = nullptr; a.K2 = 0;
   a.group_m = g_gemm_group_m;
   a.seq_off = d->seq_off; a.seq_tok0 = d->seq_tok0; a.seq_ops = d->seq_ops;
-  a.colsum = d->colsum; a.colsum_row0 = d->colsum_row0;
-  if (d->colsum && (d->batch != 1 || d->beta != 0.f || d->colsum_row0 < 0)) return PG_ERR_ARG;
   if (d->seq_off) {
     // sequence zo of every (zo, zi) batch has its own M = K <= the descriptor's: whole 64-row tiles of a
     // score-shaped operand are walked (zeros past the extent), token-row operands are clamped

@@ -161,9 +161,15 @@ def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tens
 
 def fill_temperatures(hp: GanHyper) -> List[float]:
     """The per-iteration temperatures one blind-mode fake batch draws (fully_masked_train.py:223):
-    one CPU `torch.rand(1)` per pass of the `while rate > 0` loop, whose length is fixed by the
-    rate schedule (the early exit can only trigger once every mask is gone, i.e. after the
-    fill-all pass that ends the schedule)."""
+    one CPU `torch.rand(1)` per pass of the `while rate > 0` loop, all ten of the rate schedule.
+
+    The reference's loop stops drawing for a batch once that batch has no mask left
+    (fully_masked_train.py:244-248, 10p_train.py:178-182).  That happens before the schedule ends when every
+    row of the batch is short: a blind row with fewer than ten open positions, or a seeded row whose mask count
+    is at most nine times its per-pass quota, is complete after nine passes or fewer.  The stacked fill still
+    takes the full schedule's draws for such a batch, so from that point on the CPU generator is one or more
+    draws ahead of the one-after-the-other order (later temperatures and gradient-penalty alphas differ); the
+    tokens of the batch itself are not affected, it had nothing left to fill."""
     temps, rate = [], hp.initial_masking_rate
     while rate > 0:
         temps.append(hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp))
@@ -434,8 +440,9 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
     if one_forward:
         if not trainable:
             raise ValueError("one_forward needs the encoder and the head trainable")
-        real = critic.protbert._check_ids(real_data)
-        fk = critic.protbert._check_ids(fake)
+        # (ids here come from the tokenizer and from the fill kernels: no read-back of their range per update)
+        real = critic.protbert._check_ids(real_data, values=False)
+        fk = critic.protbert._check_ids(fake, values=False)
         if real.shape != fk.shape:
             raise ValueError(f"real {tuple(real.shape)} and fake {tuple(fk.shape)} batches differ in shape")
         if ragged is None:

@@ -600,6 +600,31 @@ def test_bf16_generation_runs_and_is_plausible(pg):
     assert len(out) == 6 and all(isinstance(s, str) for s in out)
 
 
+def test_token_ids_outside_the_vocabulary_raise(pg):
+    """torch's embedding raises on an id that is no row of the table (the reference's BertEmbeddings lookup);
+    the engine checks before it launches, in the model forward, the fill step and the gradient penalty."""
+    c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
+    m = gen.protbert
+    V = m.config.vocab_size
+    ids = torch.randint(5, 25, (2, 12), device=DEV)
+    m(input_ids=ids)
+    for bad in (V, -1):
+        wrong = ids.clone()
+        wrong[1, 3] = bad
+        with pytest.raises(IndexError):
+            m(input_ids=wrong)
+        with pytest.raises(IndexError):
+            gen.generate(wrong.clone(), torch.ones_like(wrong), keep_percent=0.1, current_rate=0.9)
+        with pytest.raises(IndexError):
+            pg.compute_gradient_penalty(critic, wrong, ids, torch.ones(2, 12, device=DEV), torch.ones(2, 12, device=DEV), DEV)
+    # a buffer that passed once and is then changed through torch is looked at again
+    buf = ids.clone()
+    m(input_ids=buf)
+    buf[0, 0] = V
+    with pytest.raises(IndexError):
+        m(input_ids=buf)
+
+
 # ----------------------------------------------------------------------------- full-size ProtBERT
 FULL = O.BertCfg(max_position_embeddings=640)  # 30 x 1024 x 16 heads x 4096, vocab 30
 
