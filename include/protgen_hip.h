@@ -258,6 +258,10 @@ int pg_softmax_bwd2(int dtype, const void* P, const void* Sdot, const float* gP,
 /* logits[t][v] = hidden_t . word[v] + bias[v] (tied decoder, modeling_bert.py:484-496), fp32 out. */
 int pg_mlm_decode(int dtype, const void* t, const float* word, const float* bias, float* logits, int T, int H, int V,
                   void* stream);
+/* Backward of pg_mlm_decode: dt[T][H] = dlogits word (when dt != NULL); gword[V][H] += dlogits^T t and
+ * gbias[V] += column sums of dlogits (when gword != NULL; fp32 atomics).  V <= 64. */
+int pg_mlm_decode_bwd(int dtype, const float* dlogits, const void* t, const float* word, void* dt, float* gword,
+                      float* gbias, int T, int H, int V, void* stream);
 /* Per token: p = softmax(logits/temperature); pred = argmax_v p_v / noise_v (== torch.multinomial
  * under the same Exp(1) draw); conf = p[pred].  noise fp32 [T][V].                       */
 int pg_sample_tokens(const float* logits, const float* noise, float temperature, int T, int V, int64_t* pred,
@@ -393,6 +397,14 @@ int pg_encoder_forward_ragged(const pg_model_cfg* cfg, const pg_params* p, int d
 /* MLM head up to logits (Generator.forward, models.py:14-16): fp32 logits [T][V]. */
 int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T, void* workspace,
                   int64_t workspace_bytes, float* logits, void* stream);
+/* Backward of pg_mlm_logits (the reference takes it from autograd when the generator's logits feed a loss:
+ * docs/HISTORY.md:169-179; head = BertOnlyMLMHead, tied decoder).  dlogits fp32 [T][V]; dhidden [T][H] in the
+ * activation type.  With param_grads, the gradients of the head's dense, LayerNorm, decoder bias and of the tied
+ * word-embedding table are added into p->grad.  Nothing of the forward is kept: the head is evaluated again. */
+int64_t pg_mlm_backward_workspace_bytes(const pg_model_cfg* cfg, int dtype, int T);
+int pg_mlm_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T,
+                    const float* dlogits, int param_grads, void* dhidden, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 /* First-order backward of pg_encoder_forward from d_hidden [B,S,H] (activation dtype).
  * flags: bit0 = accumulate parameter gradients into p->grad; bit1 = write every layer's
  * adjoints into adj_stash (same layout as the forward stash; needed by the GP).

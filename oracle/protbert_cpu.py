@@ -333,6 +333,22 @@ def critic_step_grads(P, C, cfg, real, fake, real_mask, fake_mask, alpha, lambda
     return loss.detach(), gp.detach(), rs.detach(), fs.detach(), grads
 
 
+def generator_soft_step_grads(PG, PC, C, cfg, masked_ids, mask, temperature=1.0, critic_mask=None):
+    """The differentiable generator update docs/HISTORY.md:169-179 prescribes (restated from its snippet; the
+    reference's trainers do not contain it yet, so no run of the reference pins it): softmax(logits / T) of the
+    generator over the masked template, averaged word embeddings of the critic, the critic's 3-D branch
+    (models.py:94-102), generator_loss.  Returns (g_loss, grads over the generator's parameter names; parameters
+    the loss does not reach are absent)."""
+    Pl = {k: v.detach().clone().requires_grad_(True) for k, v in PG.items()}
+    logits = generator_forward(Pl, cfg, masked_ids, mask)
+    soft = F.softmax(logits / temperature, dim=-1) @ PC["bert.embeddings.word_embeddings.weight"]
+    scores = critic_forward(PC, C, cfg, soft, mask if critic_mask is None else critic_mask)
+    loss = generator_loss(scores)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in Pl.items() if v.grad is not None}
+
+
+
 def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01):
     """torch.optim.AdamW single-tensor update (decoupled weight decay), in place; `step`
     is the 1-based step count after increment."""

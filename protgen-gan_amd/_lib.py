@@ -95,6 +95,7 @@ SIGNATURES = {
     "pg_softmax_jvp": (i32, [i32, vp, vp, vp, vp, i32, i32, vp]),
     "pg_softmax_bwd2": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "pg_mlm_decode": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "pg_mlm_decode_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "pg_sample_tokens": (i32, [vp, vp, f32, i32, i32, vp, vp, vp]),
     "pg_commit_topk": (i32, [vp, vp, vp, i32, i32, f64, i32, i32, i32, i32, i32, vp, vp]),
     "pg_head_stash_floats": (i64, [i32]),
@@ -114,6 +115,8 @@ SIGNATURES = {
     "pg_stash_bytes": (i64, [cfgp, i32, i32, i32]),
     "pg_encoder_forward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "pg_mlm_logits": (i32, [cfgp, parp, i32, vp, i32, vp, i64, vp, vp]),
+    "pg_mlm_backward_workspace_bytes": (i64, [cfgp, i32, i32]),
+    "pg_mlm_backward": (i32, [cfgp, parp, i32, vp, i32, vp, i32, vp, vp, i64, vp]),
     "pg_encoder_backward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i32, i32, i32, ragp]),
     "pg_encoder_forward_ragged": (i32, [cfgp, parp, i32, i32, ragp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "pg_workspace_bytes_ragged": (i64, [cfgp, i32, i32, i32, i32]),

@@ -222,6 +222,36 @@ class _EncoderFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), None, None, None
 
 
+class _MlmHeadFn(torch.autograd.Function):
+    """The MLM head with a backward (dense -> GELU -> LayerNorm -> tied decoder + bias): the head is evaluated again
+    in the backward, so only `hidden` is kept."""
+
+    @staticmethod
+    def forward(ctx, hidden, model, _sentinel):
+        ctx.model, ctx.hidden = model, hidden
+        ctx.grads = ctx.needs_input_grad[2]
+        return model._lm_logits_raw(hidden)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m, hidden = ctx.model, ctx.hidden
+        B, S, H = hidden.shape
+        T = B * S
+        if ctx.grads:
+            m._reach_head()
+            m.store.begin_accumulate()
+        dt = ops.dt_code(m.compute_dtype)
+        n = lib.pg_mlm_backward_workspace_bytes(C.byref(m._ccfg), dt, T)
+        ws = workspace(m.device, n)
+        dhidden = torch.empty_like(hidden)
+        pr = _params_struct(m.store, m.compute_dtype, ctx.grads)
+        check(lib.pg_mlm_backward(C.byref(m._ccfg), C.byref(pr), dt, hidden.data_ptr(), T,
+                                  dlogits.to(torch.float32).contiguous().data_ptr(), 1 if ctx.grads else 0,
+                                  dhidden.data_ptr(), ws.data_ptr(), n, ops.stream()), "pg_mlm_backward")
+        ctx.hidden = None
+        return (dhidden if ctx.needs_input_grad[0] else None), None, None
+
+
 # ----------------------------------------------------------------------------- module tree
 class _Node(nn.Module):
     """Name-only container so parameters carry HuggingFace's dotted names."""
@@ -668,7 +698,29 @@ class ProtBertForMaskedLM(nn.Module):
 
     def lm_logits(self, hidden, ws_shape=None):
         """MLM head (dense -> GELU -> LayerNorm -> tied decoder + bias) -> fp32 [B,S,V].
-        `ws_shape`: the (B, S) whose workspace is large enough (packed rows: the unpacked shape)."""
+        `ws_shape`: the (B, S) whose workspace is large enough (packed rows: the unpacked shape).
+        Under autograd (a hidden state that carries a graph, or head parameters that take gradients) the
+        logits carry the head's backward."""
+        if torch.is_grad_enabled() and (hidden.requires_grad or self._head_sentinel().requires_grad):
+            return _MlmHeadFn.apply(hidden.contiguous(), self, self._head_sentinel())
+        return self._lm_logits_raw(hidden, ws_shape)
+
+    def _head_sentinel(self):
+        return self.cls.predictions.transform.dense.weight
+
+    def _reach_head(self):
+        """The MLM head's parameters join the ones a backward can reach the first time a head backward runs.
+        (Until then they have no .grad, like the head of a model whose logits never feed a loss: the optimizer
+        leaves such parameters alone, weight decay included.)"""
+        if not getattr(self, "_head_reached", False):
+            for name, _ in _GLOBAL_NAMES:
+                if name.startswith("cls."):
+                    p = self.get_parameter(name)
+                    _, off, n = p._pg_store
+                    self.store.views.append((p, off, n))
+            self._head_reached = True
+
+    def _lm_logits_raw(self, hidden, ws_shape=None):
         B, S, H = hidden.shape
         T = B * S
         ws, n = self._ws(*(ws_shape or (B, S)))

@@ -559,6 +559,55 @@ extern "C" int pg_mlm_logits(const pg_model_cfg* cfg, const pg_params* p, int dt
                        pv.m(pg_param_offset_global(cfg, PG_P_MLM_BIAS)), logits, T, H, cfg->vocab_size, st);
 }
 
+// MLM head, backward.  Nothing of the forward is kept: u = hidden W^T + b, gelu(u) and the LayerNorm output are
+// computed again here (one H x H product, against the encoder's 30 layers).
+//   dt = dlogits word ; g_word += dlogits^T t ; g_bias += colsum(dlogits)
+//   dg = LN'(gelu(u))^T dt (+ g_gamma, g_beta) ; du = dg * gelu'(u) ; g_b += colsum(du) ; g_W += du^T hidden
+//   dhidden = du W
+extern "C" int64_t pg_mlm_backward_workspace_bytes(const pg_model_cfg* cfg, int dtype, int T) {
+  if (!cfg || T <= 0) return -1;
+  const int es = dtype == PG_F32 ? 4 : 2;
+  return 4 * align_up((long)T * cfg->hidden * es, 256) + align_up(3L * cfg->hidden * pg_ln_partial_rows(T) * 4, 256);
+}
+
+extern "C" int pg_mlm_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, const void* hidden, int T,
+                               const float* dlogits, int param_grads, void* dhidden, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  if (!cfg || !p || !p->master || !hidden || !dlogits || !dhidden || !workspace || T <= 0) return PG_ERR_ARG;
+  if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
+  if (param_grads && !p->grad) return PG_ERR_ARG;
+  if (pg_mlm_backward_workspace_bytes(cfg, dtype, T) > workspace_bytes) return PG_ERR_WORKSPACE;
+  const int H = cfg->hidden, V = cfg->vocab_size, es = dtype == PG_F32 ? 4 : 2;
+  const long sz = align_up((long)T * H * es, 256);
+  char* u = (char*)workspace;       // pre-GELU
+  char* gl = u + sz;                // gelu(u), later du
+  char* t = gl + sz;                // LayerNorm output, later dt
+  char* dg = t + sz;
+  float* partial = (float*)(dg + sz);
+  hipStream_t st = (hipStream_t)stream;
+  ParamView pv{cfg, p, dtype};
+  G g{dtype, st};
+  auto go = [&](int which) { return pg_param_offset_global(cfg, which); };
+  auto gr = [&](int which) -> float* { return param_grads ? pv.g(go(which)) : nullptr; };
+  CK(g.run(hidden, true, H, pv.w(go(PG_P_MLM_W)), true, H, gl, dtype, H, T, H, H, 1.f, 0.f, pv.m(go(PG_P_MLM_B)), nullptr, 0,
+           PG_ACT_GELU, u, H));
+  if (param_grads)
+    CK(pg_layernorm(dtype, gl, pv.m(go(PG_P_MLM_LN_G)), pv.m(go(PG_P_MLM_LN_B)), cfg->ln_eps, t, T, H, st));
+  // the decoder's weight gradient reads t before dt takes its place
+  if (param_grads)
+    CK(pg_mlm_decode_bwd(dtype, dlogits, t, nullptr, nullptr, gr(PG_P_WORD_EMB), gr(PG_P_MLM_BIAS), T, H, V, st));
+  CK(pg_mlm_decode_bwd(dtype, dlogits, nullptr, pv.m(go(PG_P_WORD_EMB)), t, nullptr, nullptr, T, H, V, st));
+  CK(pg_layernorm_bwd(dtype, gl, t, pv.m(go(PG_P_MLM_LN_G)), cfg->ln_eps, dg, gr(PG_P_MLM_LN_G), gr(PG_P_MLM_LN_B), nullptr,
+                      partial, T, H, st));
+  char* du = gl;
+  CK(pg_gelu_bwd2(dtype, u, nullptr, nullptr, dg, du, (int64_t)T * H, st));
+  if (param_grads) {
+    CK(pg_colsum_acc(dtype, du, H, T, H, gr(PG_P_MLM_B), st));
+    CK(g.dw(g.dw_desc(du, hidden, gr(PG_P_MLM_W), H, H, T)));
+  }
+  return g.run(du, true, H, pv.w(go(PG_P_MLM_W)), false, H, dhidden, dtype, H, T, H, H, 1.f, 0.f);
+}
+
 // ------------------------------------------------------------------ first-order backward
 extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                                    void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,

@@ -50,8 +50,77 @@ __global__ __launch_bounds__(1024) void mlm_decode_kernel(const T* __restrict__ 
   }
 }
 
-// ------------------------------------------------------------------ sampler: one thread per token
 constexpr int MAXV = 64;
+
+// ------------------------------------------------------------------ tied MLM decoder, backward
+// dt[t][h] = sum_v dl[t][v] * word[v][h].  A block takes 16 token rows, whose dl rows sit in LDS; a thread owns
+// the columns h, h + 256, ... and walks the V rows of the table (coalesced, served by L2 after the first block).
+template <typename T>
+__global__ __launch_bounds__(256) void mlm_decode_bwd_x_kernel(const float* __restrict__ dl, const float* __restrict__ word,
+                                                               T* __restrict__ dt, int Tn, int H, int V) {
+  constexpr int ROWS = 16;
+  __shared__ float s[ROWS * MAXV];
+  const long t0 = (long)blockIdx.x * ROWS;
+  const int rows = (int)min((long)ROWS, (long)Tn - t0);
+  for (int i = threadIdx.x; i < ROWS * MAXV; i += blockDim.x) {
+    const int r = i / MAXV, v = i % MAXV;
+    s[i] = (r < rows && v < V) ? dl[(t0 + r) * V + v] : 0.f;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int v = 0; v < V; ++v) {
+      const float w = word[(long)v * H + h];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) acc[r] += s[r * MAXV + v] * w;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+      if (r < rows) dt[(t0 + r) * H + h] = from_f32<T>(acc[r]);
+  }
+}
+
+// gword[v][h] += sum_t dl[t][v] * x[t][h] ; gbias[v] += sum_t dl[t][v].  A block takes a span of token rows and 256
+// columns; a thread owns one column and keeps one partial sum per vocabulary entry, added to the fp32 gradients
+// with atomics at the end (blocks of different spans meet there).
+template <typename T>
+__global__ __launch_bounds__(256) void mlm_decode_bwd_w_kernel(const float* __restrict__ dl, const T* __restrict__ x,
+                                                               float* __restrict__ gword, float* __restrict__ gbias, int Tn,
+                                                               int H, int V, int span) {
+  constexpr int CH = 16;
+  __shared__ float s[CH * MAXV];
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  const long t0 = (long)blockIdx.y * span, t1 = min((long)Tn, t0 + span);
+  float acc[MAXV];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) acc[v] = 0.f;
+  float bsum = 0.f;
+  for (long tc = t0; tc < t1; tc += CH) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < CH * MAXV; i += blockDim.x) {
+      const int r = i / MAXV, v = i % MAXV;
+      s[i] = (tc + r < t1 && v < V) ? dl[(tc + r) * V + v] : 0.f;
+    }
+    __syncthreads();
+    const int rows = (int)min((long)CH, t1 - tc);
+    for (int r = 0; r < rows; ++r) {
+      const float xv = h < H ? to_f32<T>(x[(tc + r) * H + h]) : 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) acc[v] += s[r * MAXV + v] * xv;
+      if (blockIdx.x == 0 && threadIdx.x < MAXV) bsum += s[r * MAXV + threadIdx.x];
+    }
+  }
+  if (h < H) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+      if (v < V) atomicAdd(gword + (long)v * H + h, acc[v]);
+  }
+  if (gbias && blockIdx.x == 0 && (int)threadIdx.x < V) atomicAdd(gbias + threadIdx.x, bsum);
+}
+
+// ------------------------------------------------------------------ sampler: one thread per token
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
                                                       float temperature, int Tn, int V, int64_t* __restrict__ pred,
                                                       float* __restrict__ conf) {
@@ -521,6 +590,34 @@ extern "C" int pg_mlm_decode(int dtype, const void* t, const float* word, const 
     default: return PG_ERR_UNSUPPORTED;                       \
   }
   if (dtype == PG_F32) { DECODE_DISPATCH(float) } else { DECODE_DISPATCH(bf16_t) }
+  return check_launch();
+}
+
+extern "C" int pg_mlm_decode_bwd(int dtype, const float* dlogits, const void* t, const float* word, void* dt, float* gword,
+                                 float* gbias, int T, int H, int V, void* stream) {
+  if (!dlogits || T <= 0 || H <= 0 || V <= 0 || V > MAXV) return PG_ERR_ARG;
+  if ((dt && !word) || ((gword || gbias) && !t) || (gbias && !gword)) return PG_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt) {
+    const int blocks = (T + 15) / 16;
+    if (dtype == PG_F32)
+      hipLaunchKernelGGL(mlm_decode_bwd_x_kernel<float>, dim3(blocks), dim3(256), 0, st, dlogits, word, (float*)dt, T, H, V);
+    else
+      hipLaunchKernelGGL(mlm_decode_bwd_x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, dlogits, word, (bf16_t*)dt, T, H, V);
+  }
+  if (gword) {
+    int spans = (T + 63) / 64;
+    if (spans > 128) spans = 128;
+    const int span = ((T + spans - 1) / spans + 15) / 16 * 16;
+    spans = (T + span - 1) / span;
+    const dim3 grid((H + 255) / 256, spans);
+    if (dtype == PG_F32)
+      hipLaunchKernelGGL(mlm_decode_bwd_w_kernel<float>, grid, dim3(256), 0, st, dlogits, (const float*)t, gword, gbias, T, H, V,
+                         span);
+    else
+      hipLaunchKernelGGL(mlm_decode_bwd_w_kernel<bf16_t>, grid, dim3(256), 0, st, dlogits, (const bf16_t*)t, gword, gbias, T, H,
+                         V, span);
+  }
   return check_launch();
 }
 

@@ -477,9 +477,67 @@ def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0) -> torc
     return g_loss.detach()
 
 
+class _frozen_parameters:
+    """Parameters of `module` take no gradient inside the block (their requires_grad flags come back after)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+def generator_update_soft(generator: Generator, critic: Critic, gen_optimizer, masked_input_ids, attention_mask,
+                          temperature: float = 1.0, critic_attention_mask=None, grad_sync=None,
+                          critic_param_grads: bool = False) -> torch.Tensor:
+    """The generator update the reference's history prescribes in place of the one above
+    (docs/HISTORY.md:169-179): the generator's logits over the masked template become probabilities, the
+    probabilities average the critic's word-embedding rows, and the critic scores those embeddings through its
+    3-D branch (models.py:94-102), so the loss reaches the generator's weights: MLM head, encoder, embeddings.
+
+    The critic's own parameters would collect a gradient on the way (the snippet leaves them trainable) that its
+    next update throws away; `critic_param_grads=False` skips that work, the generator's gradients are the same.
+    `grad_sync`: called between backward and the optimizer step (data-parallel average of the generator's
+    gradients)."""
+    gen_optimizer.zero_grad()
+    logits = generator.protbert(input_ids=masked_input_ids, attention_mask=attention_mask).logits
+    soft_probs = F.softmax(logits / temperature, dim=-1)
+    table = critic.protbert.bert.embeddings.word_embeddings.weight
+    cmask = attention_mask if critic_attention_mask is None else critic_attention_mask
+    if critic_param_grads:
+        fake_scores = critic(soft_probs @ table, attention_mask=cmask)
+    else:
+        with _frozen_parameters(critic):
+            fake_scores = critic(soft_probs @ table.detach(), attention_mask=cmask)
+    g_loss = generator_loss(fake_scores)
+    if g_loss.requires_grad:  # (not in the frozen first epoch: freeze_protbert leaves the generator nothing to train)
+        g_loss.backward()
+        if grad_sync is not None:
+            grad_sync()
+    gen_optimizer.step()
+    return g_loss.detach()
+
+
+def blind_template(lengths: Sequence[int], device, mask_id=4, cls_id=2, sep_id=3, pad_id=0) -> torch.Tensor:
+    """`[CLS] MASK.. [SEP] PAD..` rows of the given lengths (CLS and SEP included), as wide as the longest
+    (fully_masked_train.py:203-215)."""
+    ids = torch.full((len(lengths), max(lengths)), pad_id, dtype=torch.long)
+    for i, L in enumerate(lengths):
+        ids[i, :L] = mask_id
+        ids[i, 0] = cls_id
+        ids[i, L - 1] = sep_id
+    return ids.to(device)
+
+
 def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                    real_batches: List[dict], length_pool: Sequence[int], hp: GanHyper, batch_size: int, device,
-                   rng=random, grad_sync=None, stacked_generation: bool = True):
+                   rng=random, grad_sync=None, stacked_generation: bool = True, soft_generator_update: bool = False,
+                   gen_grad_sync=None):
     """One iteration of the blind-mode training loop: n_critic critic updates (each with a
     fresh fake batch) followed by one generator update on `gen_batch_blind` fakes.
 
@@ -487,8 +545,15 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     generator_update), so with `stacked_generation` all n_critic + 1 fake batches are filled
     up front as one stacked batch.  The host random draws are made in the order the
     one-after-the-other loop makes them (lengths from `rng`; temperatures and the
-    gradient-penalty alpha from the CPU torch generator)."""
+    gradient-penalty alpha from the CPU torch generator).
+
+    `soft_generator_update`: the generator update is generator_update_soft on the fully masked template of the
+    generator batch (keys visible as in the fill: `ids != MASK`; the critic sees `ids != PAD`), at the first
+    temperature drawn for that batch; the batch is not filled.  The generator then changes every iteration, which
+    the stacked fill allows: all fills of an iteration happen before its generator update."""
     real_batches = real_batches[:hp.n_critic]
+    if soft_generator_update and not stacked_generation:
+        raise ValueError("the soft generator update is wired into the stacked form only")
     if not stacked_generation:
         c_sum = None
         for batch in real_batches:
@@ -506,32 +571,56 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
         alphas.append(torch.rand(batch["input_ids"].size(0), 1, 1))
     lengths.append([sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(hp.gen_batch_blind)])
     temps.append(fill_temperatures(hp))
-    fakes = generate_fake_batches(generator, lengths, temps, hp, device)
+    n_fill = len(lengths) - (1 if soft_generator_update else 0)
+    fakes = generate_fake_batches(generator, lengths[:n_fill], temps[:n_fill], hp, device)
     c_sum = None
     for batch, fake, alpha, fl in zip(real_batches, fakes, alphas, lengths):
         # (a fake row's non-pad columns end inside its template: positions past it are never masks, so never filled)
         c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
                           grad_sync=grad_sync, alpha=alpha, real_lengths=batch.get("lengths"), fake_lengths=fl)
         c_sum = c if c_sum is None else c_sum + c
-    g = generator_update(critic, gen_optimizer, fakes[-1])
+    if soft_generator_update:
+        tpl = blind_template([min(L, hp.max_len) for L in lengths[-1]], device)
+        width = tpl.size(1)
+        if width % 8:  # the backward passes want a multiple of 8 columns: pad columns no key mask lets in
+            tpl = F.pad(tpl, (0, 8 - width % 8), value=0)
+        visible = (tpl != 4)
+        visible[:, width:] = False
+        g = generator_update_soft(generator, critic, gen_optimizer, tpl, visible.long(), temperature=temps[-1][0],
+                                  critic_attention_mask=(tpl != 0).long(), grad_sync=gen_grad_sync)
+    else:
+        g = generator_update(critic, gen_optimizer, fakes[-1])
     return c_sum / hp.n_critic, g
 
 
 def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                     real_batches: List[dict], gen_batches: List[dict], hp: GanHyper, grad_sync=None,
-                    stacked_generation: bool = True):
+                    stacked_generation: bool = True, soft_generator_update: bool = False, gen_grad_sync=None):
     """One iteration of the seeded-mode loop (10p_train.py:296-370): needs n_critic critic
     batches and n_critic + 1 generator batches.  With `stacked_generation` the n_critic + 1 fake
     batches are filled up front as one stacked batch (generate_fakes_for_batches)."""
     c_sum = None
+    if soft_generator_update and not stacked_generation:
+        raise ValueError("the soft generator update is wired into the stacked form only")
     if stacked_generation:
-        fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:hp.n_critic + 1]], hp)
+        n_fill = hp.n_critic + (0 if soft_generator_update else 1)
+        fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:n_fill]], hp)
         for batch, fake, gb in zip(real_batches[:hp.n_critic], fakes, gen_batches):
             # (a seeded fake keeps the pad columns of the sequence it started from)
             c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
                               grad_sync=grad_sync, real_lengths=batch.get("lengths"), fake_lengths=gb.get("lengths"))
             c_sum = c if c_sum is None else c_sum + c
-        g = generator_update(critic, gen_optimizer, fakes[hp.n_critic])
+        if soft_generator_update:
+            # the generator batch masked as a fill would mask it (10p_train.py:137-145), one pass, keys `ids != PAD`
+            x = gen_batches[hp.n_critic]["input_ids"]
+            meaningful = (x != 0) & (x != 1) & (x != 2) & (x != 3)
+            tpl = x.clone()
+            tpl[meaningful & (torch.rand(x.shape, device=x.device) < hp.initial_masking_rate)] = 4
+            temperature = hp.min_temp + torch.rand(1).item() * (hp.max_temp - hp.min_temp)
+            g = generator_update_soft(generator, critic, gen_optimizer, tpl, (tpl != 0).long(), temperature=temperature,
+                                      grad_sync=gen_grad_sync)
+        else:
+            g = generator_update(critic, gen_optimizer, fakes[hp.n_critic])
         return c_sum / hp.n_critic, g
     for batch, gb in zip(real_batches[:hp.n_critic], gen_batches[:hp.n_critic]):
         fake = generate_fakes_for_batch(generator, gb["input_ids"], hp)

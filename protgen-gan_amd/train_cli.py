@@ -145,12 +145,14 @@ def fit(steps: Steps, mode: str, n_epochs: int, lr_critic: float, first_epoch: i
 # ----------------------------------------------------------------------------- the engine behind the interface
 class EngineSteps(Steps):
     def __init__(self, pg, args, generator, critic, gen_opt, critic_opt, data, pool, tokenizer, device, rank, world,
-                 grad_sync, log=print):
+                 grad_sync, log=print, gen_grad_sync=None):
         from . import train as T
         self.pg, self.T, self.args = pg, T, args
         self.generator, self.critic, self.gen_opt, self.critic_opt = generator, critic, gen_opt, critic_opt
         self.data, self.pool, self.tokenizer, self.device = data, pool, tokenizer, device
         self.rank, self.world, self.grad_sync, self.log = rank, world, grad_sync, log
+        self.gen_grad_sync = gen_grad_sync
+        self.soft = bool(getattr(args, "soft_generator_update", False))
         self.n_critic = args.n_critic
         self.hp = T.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.max_len,
                              gen_batch_blind=GEN_BATCH_BLIND)
@@ -182,7 +184,9 @@ class EngineSteps(Steps):
         T, hp = self.T, self.hp
         if with_generator_update:
             c, g = T.gan_step_blind(self.generator, self.critic, self.gen_opt, self.critic_opt, list(real_batches), self.pool,
-                                    hp, self.args.batch_size, self.device, rng=self.py_rng, grad_sync=self._sync())
+                                    hp, self.args.batch_size, self.device, rng=self.py_rng, grad_sync=self._sync(),
+                                    soft_generator_update=self.soft,
+                                    gen_grad_sync=self.gen_grad_sync if self.world > 1 else None)
             self.updates += len(real_batches)
             return float(c), float(g)
         # the incomplete last group of an epoch: its critic updates only
@@ -201,7 +205,9 @@ class EngineSteps(Steps):
         n = len(real_batches)
         if n == hp.n_critic and gen_update_batch is not None:
             c, g = T.gan_step_seeded(self.generator, self.critic, self.gen_opt, self.critic_opt, list(real_batches),
-                                     list(gen_batches) + [gen_update_batch], hp, grad_sync=self._sync())
+                                     list(gen_batches) + [gen_update_batch], hp, grad_sync=self._sync(),
+                                     soft_generator_update=self.soft,
+                                     gen_grad_sync=self.gen_grad_sync if self.world > 1 else None)
             self.updates += n
             return float(c), float(g)
         fakes = T.generate_fakes_for_batches(self.generator, [gb["input_ids"] for gb in gen_batches], hp)
@@ -235,6 +241,8 @@ class EngineSteps(Steps):
         self.generator.protbert.save_pretrained(os.path.join(d, "generator_bert"))
         if not self.args.no_optimizer_state:
             torch.save(self.critic_opt.state_dict(), os.path.join(d, "critic_optimizer.pt"))
+            if self.soft:  # (otherwise the generator's optimizer never holds a moment)
+                torch.save(self.gen_opt.state_dict(), os.path.join(d, "generator_optimizer.pt"))
         with open(os.path.join(d, "trainer_state.json"), "w") as fh:
             json.dump({"epoch": epoch + 1, "mode": self.args.mode, "critic_updates": self.updates}, fh)
         self.log(f"epoch {epoch + 1}: checkpoint in {d}")
@@ -265,6 +273,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--resume", default=None, help="an epoch_<n> checkpoint directory of a previous run")
     ap.add_argument("--no_optimizer_state", action="store_true", help="checkpoints as the reference writes them (weights only)")
+    ap.add_argument("--soft_generator_update", action="store_true",
+                    help="generator update through soft embeddings and the critic's 3-D branch (gradients reach the generator) "
+                         "instead of the reference loop's update on token ids (which reaches the critic only)")
     return ap
 
 
@@ -311,13 +322,20 @@ def main(argv=None):
     opt_state = os.path.join(args.resume, "critic_optimizer.pt") if args.resume else None
     if opt_state and os.path.exists(opt_state):
         critic_opt.load_state_dict(torch.load(opt_state, weights_only=True))
+    gen_state = os.path.join(args.resume, "generator_optimizer.pt") if args.resume else None
+    if gen_state and os.path.exists(gen_state):
+        gen_bert._reach_head()  # the saved moments cover the MLM head
+        gen_opt.load_state_dict(torch.load(gen_state, weights_only=True))
 
     data = D.TokenizedSet.from_file(args.data_file, tokenizer, args.max_len)
     pool = D.length_pool(args.lengths_file) if args.mode == "blind" else [n - 2 for n in data.lengths]
     sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world, overlap=critic.protbert,
                         position_rows=args.max_len)
+    gen_sync = None
+    if args.soft_generator_update:
+        gen_sync = pgd.GradSync([generator.protbert.store], world, overlap=generator.protbert, position_rows=args.max_len)
     steps = EngineSteps(pg, args, generator, critic, gen_opt, critic_opt, data, pool, tokenizer, device, rank, world, sync,
-                        log=lambda s: print(s, flush=True))
+                        log=lambda s: print(s, flush=True), gen_grad_sync=gen_sync)
     if rank == 0:
         print(f"{args.mode} mode, {len(data)} sequences, {world} GPU(s), batch {args.batch_size} per GPU, epochs "
               f"{first_epoch + 1}..{args.n_epochs}", flush=True)
