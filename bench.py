@@ -64,6 +64,9 @@ def main():
                     help="seeded = 10p_train.py's loop: fakes start from real sequences with 90 %% of the residues masked")
     ap.add_argument("--regime", choices=["unfrozen", "frozen"], default="unfrozen",
                     help="frozen = epoch 0 of the trainers: both ProtBERTs frozen, only the critic head learns")
+    ap.add_argument("--soft-generator-update", action="store_true",
+                    help="generator update through soft embeddings (gradients reach the generator and are all-reduced); "
+                         "not the reference loop's update, so not the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
     ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
@@ -127,12 +130,17 @@ def main():
         seeds = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic + 1)]
                  for _ in range(total)]
 
+    soft = args.soft_generator_update
+    gen_sync = None
+    if soft and world > 1:
+        gen_sync = pgd.GradSync([generator.protbert.store], world, overlap=generator.protbert, position_rows=args.seq)
+
     def one_step(i):
         if seeds is not None:
             return pgt.gan_step_seeded(generator, critic, gen_opt, critic_opt, real[i], seeds[i], hp,
-                                       grad_sync=sync if use_sync else None)
+                                       grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
-                                  grad_sync=sync if use_sync else None)
+                                  grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
 
     def fence():
         if world > 1:
@@ -171,6 +179,8 @@ def main():
     # forward-equivalents per critic update: unfrozen 12 (penalty 6 + real/fake forward 2 and backward 4);
     # frozen 5 (penalty forward, input gradient and tangent pass + real/fake forward; no encoder backward)
     fe_critic, fe_gen = (12, 3) if args.regime == "unfrozen" else (5, 1)
+    if soft:  # generator forward + backward with weight gradients (3), critic forward + input-gradient backward (2)
+        fe_gen = 5 if args.regime == "unfrozen" else 2
     critic_flops = args.steps * args.n_critic * fe_critic * f_c(args.batch, args.seq)
     gen_flops = args.steps * fe_gen * f_c(args.gen_batch if seeds is None else args.batch, args.seq)
     flops_step = (fill_flops + critic_flops + gen_flops) / args.steps
@@ -206,6 +216,7 @@ def main():
                                 ": one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head"),
                    "critic_batch": args.batch, "generator_batch": args.gen_batch if seeds is None else args.batch, "seq_len": args.seq, "n_critic": args.n_critic,
                    "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime,
+                   "generator_update": "soft embeddings through the critic's 3-D branch" if soft else "token ids (reference loop)",
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
                    "weights": "ProtBERT architecture, seeded random init", "lengths": f"uniform {pool[0]}..{pool[-1]} (DNMT-length stand-in)"},
         "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),

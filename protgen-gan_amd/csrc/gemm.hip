@@ -1222,6 +1222,7 @@ int g_gemm_deep_max_blocks = 256;
 int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
 
 extern int pg_internal_colsum_chunks;
+extern int pg_internal_colsum_waves;
 extern int pg_internal_dw_depth;
 extern int pg_internal_fused_dgelu_save;
 extern "C" int pg_tune(int key, int value) {
@@ -1239,6 +1240,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 14) { if (value < 1) return PG_ERR_ARG; g_gemm_wide_min_tiles = value; return PG_OK; }
   if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
+  if (key == 17) { if (value != 4 && value != 16) return PG_ERR_ARG; pg_internal_colsum_waves = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }

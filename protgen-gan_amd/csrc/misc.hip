@@ -540,6 +540,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (shadow) shadow[i] = f32_to_bf16_bits(pi);
   }
 }
+// Four parameters per lane: 16-byte accesses to p, g, m, v and 8-byte stores of the bf16 copy.
+__global__ __launch_bounds__(256) void adamw_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                          float4* __restrict__ m, float4* __restrict__ v,
+                                                          uint2* __restrict__ shadow, long n4, float lr, float b1, float b2,
+                                                          float eps, float wd, float bc1, float sqrt_bc2, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g4 = g[i];
+    float4 p4 = p[i], m4 = m[i], v4 = v[i];
+    const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+    float ps[4] = {p4.x, p4.y, p4.z, p4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = gs[e] * gscale;
+      float pi = ps[e] * (1.0f - lr * wd);
+      const float mi = ms[e] * b1 + (1.0f - b1) * gi;
+      const float vi = vs[e] * b2 + (1.0f - b2) * gi * gi;
+      const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+      pi = pi - (lr / bc1) * (mi / denom);
+      ps[e] = pi; ms[e] = mi; vs[e] = vi;
+    }
+    p[i] = make_float4(ps[0], ps[1], ps[2], ps[3]);
+    m[i] = make_float4(ms[0], ms[1], ms[2], ms[3]);
+    v[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    if (shadow) {
+      uint2 o;
+      o.x = (unsigned)f32_to_bf16_bits(ps[0]) | ((unsigned)f32_to_bf16_bits(ps[1]) << 16);
+      o.y = (unsigned)f32_to_bf16_bits(ps[2]) | ((unsigned)f32_to_bf16_bits(ps[3]) << 16);
+      shadow[i] = o;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     d[i] = f32_to_bf16_bits(s[i]);
@@ -839,8 +870,17 @@ extern "C" int pg_adamw(float* p, const float* g, float* m, float* v, void* shad
   if (!p || !g || !m || !v || n <= 0 || step < 1) return PG_ERR_ARG;
   const float bc1 = 1.0f - (float)pow((double)beta1, step);
   const float sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                     (long)n, lr, beta1, beta2, eps, wd, bc1, sqrt_bc2, grad_scale);
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0) && ((uintptr_t)shadow_bf16 % 8 == 0);
+  const long n4 = aligned ? n / 4 : 0;
+  if (n4 > 0)
+    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, (uint2*)shadow_bf16, n4, lr, beta1, beta2, eps, wd, bc1, sqrt_bc2, grad_scale);
+  const long done = n4 * 4;
+  if (done < n)
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n - done)), dim3(256), 0, st, p + done, g + done, m + done, v + done,
+                       shadow_bf16 ? (bf16_t*)shadow_bf16 + done : nullptr, (long)(n - done), lr, beta1, beta2, eps, wd, bc1,
+                       sqrt_bc2, grad_scale);
   return check_launch();
 }
 extern "C" int pg_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {

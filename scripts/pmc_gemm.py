@@ -1,6 +1,7 @@
-"""Short program for rocprofv3 --pmc passes: a few launches of the dominant GEMM shapes of the GAN step
-(fill-pass W1 with bias+GELU on the 256x256 kernel, fill-pass W2 with bias+residual, critic W2 at T=8192)."""
-import os, sys
+"""Short program for rocprofv3 --pmc passes: four launches each of the dominant GEMM shapes of the GAN step (the
+fill pass's QKV, W1 with bias+GELU, W2 and Wo with bias+residual at its packed token count; the critic's W1 and W2
+at the ragged token count of one update).  Prints each shape's operand and output bytes."""
+import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,10 @@ pg = pgload.load()
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 bf = torch.bfloat16
-for name, M, N, K, kw in [("w1_fill", 34176, 4096, 1024, "gelu"), ("w2_fill", 34176, 1024, 4096, "res"), ("w2_critic", 8192, 1024, 4096, "res")]:
+SHAPES = [("fill_qkv", 33024, 3072, 1024, "bias"), ("fill_w1", 33024, 4096, 1024, "gelu"), ("fill_w2", 33024, 1024, 4096, "res"),
+          ("fill_wo", 33024, 1024, 1024, "res"), ("critic_w1", 8064, 4096, 1024, "gelu"), ("critic_w2", 8064, 1024, 4096, "res")]
+out = []
+for name, M, N, K, kw in SHAPES:
     A = torch.randn(M, K, device=dev, generator=g).to(bf)
     B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(bf)
     C = torch.empty(M, N, dtype=bf, device=dev)
@@ -18,7 +22,11 @@ for name, M, N, K, kw in [("w1_fill", 34176, 4096, 1024, "gelu"), ("w2_fill", 34
     for _ in range(4):
         if kw == "gelu":
             pg.ops.gemm(A, B, C, bias=bias, act=1)
-        else:
+        elif kw == "res":
             pg.ops.gemm(A, B, C, bias=bias, residual=res)
+        else:
+            pg.ops.gemm(A, B, C, bias=bias)
     torch.cuda.synchronize()
-    print(name, M, N, K, "algorithmic operand+output bytes", (M * K + N * K + M * N * (2 if kw == "res" else 1)) * 2)
+    out.append({"shape": name, "M": M, "N": N, "K": K, "read_bytes": (M * K + N * K + (M * N if kw == "res" else 0)) * 2,
+                "write_bytes": M * N * 2})
+print(json.dumps(out))

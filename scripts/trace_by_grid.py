@@ -1,6 +1,6 @@
 """Aggregate a rocprofv3 kernel trace by (kernel, grid): total / count / average duration."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
 only = sys.argv[2] if len(sys.argv) > 2 else ""
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):

@@ -863,7 +863,7 @@ def test_from_pretrained_hf_written_checkpoints(pg, golden_dir):
         m = pg.ProtBertForMaskedLM.from_pretrained(os.path.join(golden_dir, d), device=DEV, compute_dtype=torch.float32)
         assert not m.training
         logits = pg.Generator(m)(ids, mask)
-        rel_close(logits.cpu().numpy(), io["logits"], 1e-4, f"logits from {d}")
+        rel_close(logits.detach().cpu().numpy(), io["logits"], 1e-4, f"logits from {d}")
 
 
 def _tiny_update(pg, critic, opt, seed):
