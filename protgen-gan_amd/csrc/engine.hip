@@ -254,6 +254,7 @@ struct DwQueue {
 }  // namespace
 int pg_internal_fused_dgelu_save = 1;  // pg_tune key 15: GELU backward in the GEMM epilogue also when adjoints are kept
 int pg_internal_dw_depth = 0;  // 0 = choose by tile count; 1..4 = force (pg_tune key 13)
+int pg_internal_round_mask = 0;  // pg_tune key 18
 namespace {
 // Layers per grouped launch: the count in 1..4 whose tiles fill whole rounds of the 256 CUs best.
 inline int dw_depth(const Dims& d, int dtype) {
@@ -412,6 +413,21 @@ extern "C" int64_t pg_stash_bytes_ragged(const pg_model_cfg* cfg, int dtype, int
   return stash_layout(d).total_bytes;
 }
 
+// Precision experiments (pg_tune key 18; fp32 passes): the slots of one layer rounded to bf16 values once the layer
+// is done, token-row slots under `tok_bit`, the score slot under `score_bit`.
+static int round_layer_slots(const Slots& s, const Dims& d, int dtype, int tok_bit, int score_bit, bool with_y, hipStream_t st) {
+  if (dtype != PG_F32 || !(pg_internal_round_mask & (tok_bit | score_bit))) return PG_OK;
+  const long T = d.T;
+  if (pg_internal_round_mask & tok_bit) {
+    struct { char* p; long n; } v[] = {{s.qkv, T * 3 * d.H}, {s.ctx, T * d.H}, {s.a, T * d.H}, {s.h, T * d.H}, {s.u, T * d.I},
+                                       {s.gu, T * d.I}, {s.f, T * d.H}, {with_y ? s.y : s.x, T * d.H}};
+    for (auto& e : v)
+      if (e.p) CK(pg_round_bf16_f32((float*)e.p, e.n, st));
+  }
+  if ((pg_internal_round_mask & score_bit) && s.ss) CK(pg_round_bf16_f32((float*)s.ss, d.Z * d.Srows * d.ldS, st));
+  return PG_OK;
+}
+
 // ------------------------------------------------------------------ forward
 // Packed inference form (seq_off != NULL; bf16, ids only, nothing stashed): the B sequences have their own lengths
 // seq_off[b+1] - seq_off[b] <= S and lie back to back in T_packed token rows; every token-wise kernel
@@ -506,6 +522,7 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
     CK(g.run(s.gu, true, I, pv.w(pv.lo(l, PG_L_W2)), true, I, s.f, dtype, H, T, H, I, 1.f, 0.f, pv.m(pv.lo(l, PG_L_B2)),
              s.h, H));
     CK(pg_layernorm(dtype, s.f, pv.m(pv.lo(l, PG_L_LN2_G)), pv.m(pv.lo(l, PG_L_LN2_B)), cfg->ln_eps, s.y, T, H, st));
+    if (stash) CK(round_layer_slots(s, d, dtype, 1, 2, true, st));
     x = s.y;
   }
   if (stash && hidden_out) {
@@ -728,6 +745,7 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     }
     // dx = dqkv Wqkv + da
     CK(g.run(a.qkv, true, 3 * H, pv.w(pv.lo(l, PG_L_WQ)), false, H, a.x, dtype, H, T, H, 3 * H, 1.f, 0.f, nullptr, a.a, H));
+    if (save) CK(round_layer_slots(a, d, dtype, 4, 8, false, st));
     dy = a.x;
   }
   CK(dwq.flush());
@@ -792,6 +810,7 @@ extern "C" int pg_encoder_jvp(const pg_model_cfg* cfg, const pg_params* p, int d
              PG_ACT_MUL_DGELU, s.u, I, t.u));
     CK(g.run(t.gu, true, I, pv.w(pv.lo(l, PG_L_W2)), true, I, t.f, dtype, H, T, H, I, 1.f, 0.f, nullptr, t.h, H));
     CK(pg_layernorm_jvp(dtype, s.f, t.f, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, t.y, T, H, st));
+    CK(round_layer_slots(t, d, dtype, 16, 32, true, st));
   }
   if (hdot_out) {
     const Slots t = layer_slots((char*)tan_stash, sl, d, d.L - 1);

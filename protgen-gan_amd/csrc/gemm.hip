@@ -1224,6 +1224,7 @@ int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalt
 extern int pg_internal_colsum_chunks;
 extern int pg_internal_colsum_waves;
 extern int pg_internal_dw_depth;
+extern int pg_internal_round_mask;
 extern int pg_internal_fused_dgelu_save;
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
@@ -1238,6 +1239,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 15) { pg_internal_fused_dgelu_save = value != 0; return PG_OK; }
   if (key == 16) { if (value < 0) return PG_ERR_ARG; g_gemm_deep_max_blocks = value; return PG_OK; }
   if (key == 14) { if (value < 1) return PG_ERR_ARG; g_gemm_wide_min_tiles = value; return PG_OK; }
+  if (key == 18) { if (value < 0 || value > 63) return PG_ERR_ARG; pg_internal_round_mask = value; return PG_OK; }
   if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
   if (key == 17) { if (value != 4 && value != 16) return PG_ERR_ARG; pg_internal_colsum_waves = value; return PG_OK; }

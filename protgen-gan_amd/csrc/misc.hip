@@ -579,6 +579,10 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict_
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     d[i] = bf16_bits_to_f32(s[i]);
 }
+__global__ __launch_bounds__(256) void round_bf16_kernel(float* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    p[i] = bf16_bits_to_f32(f32_to_bf16_bits(p[i]));
+}
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ p, float s, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] *= s;
 }
@@ -892,6 +896,11 @@ extern "C" int pg_cast_f32(const void* src, float* dst, int64_t n, void* stream)
   if (!src || !dst || n <= 0) return PG_ERR_ARG;
   hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst,
                      (long)n);
+  return check_launch();
+}
+extern "C" int pg_round_bf16_f32(float* p, int64_t n, void* stream) {
+  if (!p || n <= 0) return PG_ERR_ARG;
+  hipLaunchKernelGGL(round_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, (long)n);
   return check_launch();
 }
 extern "C" int pg_scale_f32(float* p, float s, int64_t n, void* stream) {
