@@ -1207,6 +1207,7 @@ int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte 
 int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
+int g_gemm_small_grid = 0;  // most 128x128 tiles of an unbatched product that takes 128x64 tiles instead (pg_tune key 19; off)
 int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
@@ -1245,6 +1246,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 17) { if (value != 4 && value != 16) return PG_ERR_ARG; pg_internal_colsum_waves = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
+  if (key == 19) { if (value < 0) return PG_ERR_ARG; g_gemm_small_grid = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   return PG_ERR_ARG;
 }
@@ -1283,8 +1285,12 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   const bool fast = g_gemm_path != 0 && d->dtype == PG_BF16 && d->K % GBK == 0 && d->K2 % GBK == 0 && (d->a_kmajor || d->M >= 8) &&
                     (d->b_kmajor || d->N >= 8);
   const long blocks128 = (long)grid.x * grid.y * grid.z;
+  // (key 19: a product of few 128x128 tiles on 128x64 tiles, twice the workgroups.  Timed alone on cold operands
+  // the 256 rows a sparse last round of 256x256 tiles leaves over take 14 us that way against 25-30 us at K = 1024;
+  // inside the GAN step the four-buffer 128x128 kernel is the faster one, 846 against 850-854 ms per step: off)
   const bool narrow = fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (d->K2 == 0 && g_gemm_narrow == 2 && blocks128 <= 256) ||
-                              (d->K2 == 0 && g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
+                              (d->K2 == 0 && g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024) ||
+                              (d->K2 == 0 && g_gemm_narrow == 1 && d->batch == 1 && !d->seq_off && blocks128 <= g_gemm_small_grid));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
                      // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round down to

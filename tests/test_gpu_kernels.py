@@ -272,6 +272,67 @@ def test_gemm_split_last_round_two_segments(pg):
     assert torch.equal(out.cpu().double(), ref)
 
 
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("shape", [(256, 1024, 4096), (200, 392, 1024), (128, 128, 2048), (640, 1024, 1536)])
+def test_gemm_small_grid_exact(pg, ak, bk, shape):
+    """With pg_tune key 19, products of at most that many tiles of 128x128 take the 128x64-tile kernel: small-integer
+    operands, exact against fp64, ragged M and N edges, every layout; equal to the 128x128 kernel's result."""
+    from protgen_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(77)
+    M, N, K = shape
+    if not ak:
+        M = (M + 7) // 8 * 8
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    B = torch.randint(-2, 3, (N, K), generator=g).float()
+    A[:, 0] += torch.arange(M) % 5
+    B[:, K - 1] -= torch.arange(N) % 3
+    A[:, K // 2 + 1] += torch.arange(M) % 4
+    ref = A.double() @ B.double().T
+    bf = torch.bfloat16
+    Ad = (A if ak else A.T.contiguous()).to(bf).to(DEV)
+    Bd = (B if bk else B.T.contiguous()).to(bf).to(DEV)
+    lib.pg_tune(19, 64)
+    try:
+        out = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
+    finally:
+        lib.pg_tune(19, 0)
+    assert torch.equal(out.cpu().double(), ref)
+    plain = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
+    assert torch.equal(plain, out)
+
+
+def test_gemm_small_grid_epilogues(pg):
+    """bias + GELU (with the pre-activation stored), bias + residual and the GELU-derivative epilogue on the
+    128x64-tile kernel for a 256-row product, bf16 outputs, against the 128x128 kernel (same arithmetic)."""
+    from protgen_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(78)
+    bf = torch.bfloat16
+    M, N, K = 256, 1024, 1024
+    A = (torch.randn(M, K, generator=g) * 0.5).to(bf).to(DEV)
+    B = (torch.randn(N, K, generator=g) * 0.05).to(bf).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(bf).to(DEV)
+    u = torch.randn(M, N, generator=g).to(bf).to(DEV)
+
+    def run():
+        o1, aux = torch.empty(M, N, dtype=bf, device=DEV), torch.empty(M, N, dtype=bf, device=DEV)
+        pg.ops.gemm(A, B, o1, bias=bias, act=1, aux=aux)
+        o2 = pg.ops.gemm(A, B, bias=bias, residual=res)
+        o3, gu = torch.empty(M, N, dtype=bf, device=DEV), torch.empty(M, N, dtype=bf, device=DEV)
+        pg.ops.gemm(A, B, o3, act=2, aux=u, aux2=gu)
+        torch.cuda.synchronize()
+        return [o1, aux, o2, o3, gu]
+
+    lib.pg_tune(19, 64)
+    try:
+        small = run()
+    finally:
+        lib.pg_tune(19, 0)
+    plain = run()
+    for a, c in zip(small, plain):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [128, 200])
 def test_gemm_group_weight_gradients(pg, dtype, T):
