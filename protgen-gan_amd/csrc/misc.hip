@@ -250,9 +250,15 @@ __device__ __forceinline__ void block_matvec(const float* __restrict__ W, const 
 __device__ __forceinline__ void block_matvec_t(const float* __restrict__ W, const float* vin, const float* gate_act,
                                                float* yout, int n_out, int n_in) {
   for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
-    float s = 0.f;
-    for (int o = 0; o < n_out; ++o) s += W[(long)o * n_in + i] * vin[o];
-    yout[i] = (gate_act == nullptr || gate_act[i] > 0.f) ? s : 0.f;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight, not one dependent chain
+    int o = 0;
+    for (; o + 8 <= n_out; o += 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += W[(long)(o + e) * n_in + i] * vin[o + e];
+    }
+    for (; o < n_out; ++o) s[0] += W[(long)o * n_in + i] * vin[o];
+    const float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    yout[i] = (gate_act == nullptr || gate_act[i] > 0.f) ? t : 0.f;
   }
 }
 
@@ -303,10 +309,17 @@ __global__ __launch_bounds__(1024) void head_bwd_vec_kernel(const float* __restr
   block_matvec_t(head + hd.w[1], v2, a1, v1, hd.d[2], hd.d[1]);
   __syncthreads();
   if (dhidden) {
+    // (eight rows of W0 in flight per lane: one dependent chain of d1 loads is a latency walk of 200 us)
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
-      float s = 0.f;
-      for (int o = 0; o < hd.d[1]; ++o) s += head[hd.w[0] + (long)o * H + i] * v1[o];
-      dhidden[(long)b * row_stride + i] = from_f32<T>(s);
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* w0 = head + hd.w[0] + i;
+      int o = 0;
+      for (; o + 8 <= hd.d[1]; o += 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += w0[(long)(o + e) * H] * v1[o + e];
+      }
+      for (; o < hd.d[1]; ++o) s[0] += w0[(long)o * H] * v1[o];
+      dhidden[(long)b * row_stride + i] = from_f32<T>(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
     }
   }
 }

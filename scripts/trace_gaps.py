@@ -1,6 +1,6 @@
 """Idle time between consecutive kernels of a rocprofv3 kernel trace: total, and by the kernel that follows the gap."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
 busy = sum(e - s for s, e, _ in rows)
 span = rows[-1][1] - rows[0][0]
