@@ -17,6 +17,7 @@ Prints one JSON line (rank 0).  `value` is summed over ranks (weak scaling: ever
 the per-GPU step on its own data and the critic gradients are averaged over RCCL)."""
 import argparse
 import ctypes
+import glob
 import json
 import os
 import random
@@ -197,11 +198,28 @@ def main():
         v["time_share_of_gemm"] = round(v["time_share_of_gemm"] / tot_ms, 4)
     variants.sort(key=lambda v: -v["time_share_of_gemm"])
     dom = variants[0] if variants else None
+    # fabric-side bytes per launch of the dominant kernel's largest shape, from the newest counter capture committed
+    # under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/pmc_gemm.py, summarised by
+    # scripts/pmc_summary.py): counters cannot be read from inside this process
+    traffic = traffic_note = None
+    caps = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if caps:
+        try:
+            with open(caps[-1]) as fh:
+                shapes = {e["shape"]: e for e in json.load(fh)["shapes"]}
+            e = shapes.get("fill_w1")
+            if e:
+                traffic = int(e["fetch_bytes_median"] + e["write_bytes_median"])
+                traffic_note = (f"{os.path.basename(caps[-1])}: fill-pass W1 product M {e['M']} N {e['N']} K {e['K']} (the dominant "
+                                f"kernel's largest launch): fetched {e['fetch_bytes_median'] / 1e6:.0f} MB = {e['fetch_over_operands']} x its "
+                                f"operands, wrote {e['write_bytes_median'] / 1e6:.0f} MB = {e['write_over_output']} x its output")
+        except (OSError, KeyError, ValueError):
+            pass
     roofline = None
     if dom:
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
                     "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(dom["tflops"] * 1e12 / MFMA_PEAK_BF16, 4),
-                    "traffic": None, "avg_launch_us": round(dom["avg_us"], 2), "sampled_launches": dom["sampled_launches"],
+                    "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(dom["avg_us"], 2), "sampled_launches": dom["sampled_launches"],
                     "gemm_launches_total": int(nl.value)}
 
     out = {
