@@ -115,6 +115,8 @@ SIGNATURES = {
     "pg_stash_bytes": (i64, [cfgp, i32, i32, i32]),
     "pg_encoder_forward": (i32, [cfgp, parp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "pg_round_bf16_f32": (i32, [vp, i64, vp]),
+    "pg_attention_key_lists": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "pg_attention_fwd_keys": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i64, i64, vp, vp, vp]),
     "pg_mlm_logits": (i32, [cfgp, parp, i32, vp, i32, vp, i64, vp, vp]),
     "pg_mlm_backward_workspace_bytes": (i64, [cfgp, i32, i32]),
     "pg_mlm_backward": (i32, [cfgp, parp, i32, vp, i32, vp, i32, vp, vp, i64, vp]),

@@ -81,12 +81,75 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long
   }
 }
 
+// The visible keys of every sequence, in order: idx[row0 + j] = position inside the sequence of its j-th key whose
+// mask is 1, cnt[b] = their number; cnt[b] = -1 when the sequence is to be walked whole under the additive mask
+// (a mask value other than 0 / 1, or no visible key at all: the reference's softmax is then uniform over all keys).
+// A masked key has weight exactly 0 (exp(-FLT_MAX - max) = 0), so leaving it out changes no sum; a fill pass
+// that starts from a fully masked template attends 2 keys of 500 in its first iteration and half of them midway.
+__global__ __launch_bounds__(256) void key_compact_kernel(const float* __restrict__ mask, const int* __restrict__ seq_off, int S,
+                                                          int* __restrict__ idx, int* __restrict__ cnt) {
+  __shared__ int wsum[4];
+  __shared__ int bad;
+  const int b = blockIdx.x;
+  long row0 = (long)b * S;
+  int len = S;
+  if (seq_off) {
+    row0 = seq_off[b];
+    len = seq_off[b + 1] - seq_off[b];
+  }
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int running = 0;
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const int k = c0 + threadIdx.x;
+    const float m = k < len ? mask[row0 + k] : 0.f;
+    const bool vis = k < len && m == 1.f;
+    if (k < len && m != 0.f && m != 1.f) bad = 1;
+    const unsigned long long bal = __ballot(vis);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = running;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    if (vis) idx[row0 + off + before] = k;
+    running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[b] = (bad || running == 0) ? -1 : running;
+}
+
+template <int IMM>
+__device__ __forceinline__ int rd32(unsigned addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+
+// stage_tile with the key rows taken from a table in LDS (table_addr: LDS byte address of entry 0; entry k = row of
+// the k-th key of the walk, valid for every k below the 64-multiple the walk ends at).
+__device__ __forceinline__ void stage_tile_tab(const bf16_t* __restrict__ kbase, const bf16_t* __restrict__ vbase, long ld, int k0,
+                                               unsigned table_addr, bf16_t* lds_k, bf16_t* lds_v, int wid, int lane) {
+  const unsigned a = table_addr + (unsigned)((k0 + 16 * wid + (lane >> 3)) * 4);
+  const int r0 = rd32<0>(a), r1 = rd32<32>(a);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // (nothing that uses r0 / r1 may be scheduled above the wait)
+  const int c = (lane & 7) ^ (lane >> 3);
+  const int i = wid * 2;
+  __builtin_amdgcn_global_load_lds(kbase + (long)r0 * ld + c * 8, lds_k + i * 512, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(kbase + (long)r1 * ld + c * 8, lds_k + (i + 1) * 512, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(vbase + (long)r0 * ld + c * 8, lds_v + i * 512, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(vbase + (long)r1 * ld + c * 8, lds_v + (i + 1) * 512, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
                                                            bf16_t* __restrict__ ctx, int S, int heads, long ld_qkv, long ld_ctx,
-                                                           const int* __restrict__ seq_off) {
-  // [buffer][K|V] tiles, then the additive key mask (fp32) of this batch row.  One array only:
-  // a second __shared__ object would make the compiler drain the LDS-DMA before LDS reads.
-  __shared__ __align__(16) bf16_t smem[4 * TILE + 2 * MAX_S];
+                                                           const int* __restrict__ seq_off, const int* __restrict__ key_idx,
+                                                           const int* __restrict__ key_cnt) {
+  // [buffer][K|V] tiles, then the additive key mask (fp32) of this batch row, then the rows of the keys the walk
+  // visits (int).  One array only: a second __shared__ object would make the compiler drain the LDS-DMA before
+  // LDS reads.
+  __shared__ __align__(16) bf16_t smem[4 * TILE + 4 * MAX_S];
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;  // the query tiles of one head share an XCD's L2
   const int b = bh / heads, h = bh % heads;
@@ -106,6 +169,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const bf16_t* V = Q + 2 * H;
   const float* mrow = mask ? mask + row0 : nullptr;
   const int q0 = qt * QB + wid * 32;
+  // keys walked: the sequence's visible keys when a list of them came along, else all S under the additive mask
+  int Sk = S;
+  const int* kidx = nullptr;
+  if (key_cnt) {
+    const int c = key_cnt[b];
+    if (c >= 0) {
+      Sk = c;
+      kidx = key_idx + row0;
+    }
+  }
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32kk + 8g .. +8]
   bf16x8_t qf[2][2];
@@ -121,15 +194,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
   {
     float* ml = reinterpret_cast<float*>(smem + 4 * TILE);
-    const int s_pad = ((S + KT - 1) / KT) * KT;
+    int* il = reinterpret_cast<int*>(smem + 4 * TILE + 2 * MAX_S);
+    const int s_pad = ((Sk + KT - 1) / KT) * KT;
+    const int last = kidx ? kidx[Sk - 1] : Sk - 1;
     for (int k = threadIdx.x; k < s_pad; k += 256) {
       float a = 0.f;
-      if (k >= S) a = -INFINITY;                               // beyond the sequence: weight exactly 0
-      else if (mrow) a = (1.0f - mrow[k]) * -FLT_MAX;          // HF additive mask, finfo(float32).min
+      if (k >= Sk) a = -INFINITY;                              // beyond the walk: weight exactly 0
+      else if (!kidx && mrow) a = (1.0f - mrow[k]) * -FLT_MAX;  // HF additive mask, finfo(float32).min
       ml[k] = a;
+      il[k] = k < Sk ? (kidx ? kidx[k] : k) : last;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   f32x4 o[2][4];
   float m_run[2], l_run[2];
@@ -159,16 +236,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const unsigned mask_addr = smem_addr + 4 * TILE * 2;
+  const unsigned tab_addr = mask_addr + MAX_S * 4;
 
-  const int nt = (S + KT - 1) / KT;
-  stage_tile(K, ld_qkv, 0, S, smem, wid, lane);
-  stage_tile(V, ld_qkv, 0, S, smem + TILE, wid, lane);
+  const int nt = (Sk + KT - 1) / KT;
+  stage_tile_tab(K, V, ld_qkv, 0, tab_addr, smem, smem + TILE, wid, lane);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) {
       bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      stage_tile(K, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
-      stage_tile(V, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
+      stage_tile_tab(K, V, ld_qkv, (t + 1) * KT, tab_addr, nb, nb + TILE, wid, lane);
     }
     const unsigned ka = smem_addr + (t & 1) * 4 * TILE;
     const unsigned va = ka + 2 * TILE;
@@ -1101,26 +1177,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
 
 }  // namespace
 
-extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
-                                int64_t ld_qkv, int64_t ld_ctx, void* stream) {
-  if (!qkv || !ctx || B <= 0 || S <= 0 || heads <= 0) return PG_ERR_ARG;
+extern "C" int pg_attention_key_lists(const float* mask, const int32_t* seq_off, int nseq, int S, int32_t* key_idx,
+                                      int32_t* key_cnt, void* stream) {
+  if (!mask || !key_idx || !key_cnt || nseq <= 0 || S <= 0) return PG_ERR_ARG;
+  hipLaunchKernelGGL(key_compact_kernel, dim3(nseq), dim3(256), 0, (hipStream_t)stream, mask, seq_off, S, key_idx, key_cnt);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_fwd_keys(int dtype, const void* qkv, const float* mask, void* ctx, const int32_t* seq_off, int nseq,
+                                     int S, int heads, int64_t ld_qkv, int64_t ld_ctx, const int32_t* key_idx,
+                                     const int32_t* key_cnt, void* stream) {
+  if (!qkv || !ctx || nseq <= 0 || S <= 0 || heads <= 0 || ((key_idx == nullptr) != (key_cnt == nullptr))) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return PG_ERR_ALIGN;
-  dim3 grid((S + QB - 1) / QB, B * heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, S,
-                     heads, (long)ld_qkv, (long)ld_ctx, (const int*)nullptr);
+  dim3 grid((S + QB - 1) / QB, nseq * heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, S, heads,
+                     (long)ld_qkv, (long)ld_ctx, seq_off, key_idx, key_cnt);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+extern "C" int pg_attention_fwd(int dtype, const void* qkv, const float* mask, void* ctx, int B, int S, int heads,
+                                int64_t ld_qkv, int64_t ld_ctx, void* stream) {
+  return pg_attention_fwd_keys(dtype, qkv, mask, ctx, nullptr, B, S, heads, ld_qkv, ld_ctx, nullptr, nullptr, stream);
 }
 
 extern "C" int pg_attention_fwd_packed(int dtype, const void* qkv, const float* mask, void* ctx, const int32_t* seq_off,
                                        int nseq, int max_len, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
-  if (!qkv || !ctx || !seq_off || nseq <= 0 || max_len <= 0 || heads <= 0) return PG_ERR_ARG;
-  if (dtype != PG_BF16 || max_len > MAX_S) return PG_ERR_UNSUPPORTED;
-  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7)) return PG_ERR_ALIGN;
-  dim3 grid((max_len + QB - 1) / QB, nseq * heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)ctx, max_len,
-                     heads, (long)ld_qkv, (long)ld_ctx, seq_off);
-  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+  if (!seq_off) return PG_ERR_ARG;
+  return pg_attention_fwd_keys(dtype, qkv, mask, ctx, seq_off, nseq, max_len, heads, ld_qkv, ld_ctx, nullptr, nullptr, stream);
 }
 
 namespace {

@@ -75,6 +75,7 @@ struct Workspace {
   char* ss0; char* ss1;
   char* qkv; char* ctx; char* a; char* h; char* u; char* gu; char* f; char* x0; char* x1;
   float* ln_partial;
+  int32_t* key_idx; int32_t* key_cnt;  // visible-key lists of an inference pass (one int per token row, one per sequence)
   float* mlm_tmp;  // unused by the encoder passes
   // the operands a layer's weight gradients read (f, u, qkv, a), four sets: the gradients of up to four
   // layers are launched together, so a set must outlive the three layers that follow (set 0 = f, u, qkv, a)
@@ -101,6 +102,8 @@ Workspace ws_layout(const Dims& d, char* base) {
   w.x0 = take(d.T * d.H * d.es);
   w.x1 = take(d.T * d.H * d.es);
   w.ln_partial = (float*)take(3L * d.H * 1024 * 4);
+  w.key_idx = (int32_t*)take(d.T * 4);
+  w.key_cnt = (int32_t*)take((long)d.B * 4);
   w.mlm_tmp = nullptr;
   w.rf[0] = w.f; w.ru[0] = w.u; w.rqkv[0] = w.qkv; w.ra[0] = w.a;
   for (int i = 1; i < 4; ++i) {
@@ -255,6 +258,7 @@ struct DwQueue {
 int pg_internal_fused_dgelu_save = 1;  // pg_tune key 15: GELU backward in the GEMM epilogue also when adjoints are kept
 int pg_internal_dw_depth = 0;  // 0 = choose by tile count; 1..4 = force (pg_tune key 13)
 int pg_internal_round_mask = 0;  // pg_tune key 18
+int pg_internal_visible_keys = 1;  // pg_tune key 20: inference attention over the visible keys only
 namespace {
 // Layers per grouped launch: the count in 1..4 whose tiles fill whole rounds of the 256 CUs best.
 inline int dw_depth(const Dims& d, int dtype) {
@@ -474,6 +478,10 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
   } else {
     if (hipMemcpyAsync(x, x_in, (size_t)T * H * es, hipMemcpyDeviceToDevice, st) != hipSuccess) return PG_ERR_LAUNCH;
   }
+  // nothing kept for a backward: the fused attention walks each sequence's visible keys only (one list per pass)
+  const int32_t* inf_off = seq_off ? seq_off : (rag.on() ? rag.off : nullptr);
+  const bool keys = pg_internal_visible_keys && !stash && fused && mask;
+  if (keys) CK(pg_attention_key_lists(mask, inf_off, B, S, w.key_idx, w.key_cnt, st));
   for (int l = 0; l < d.L; ++l) {
     Slots s;
     if (stash) {
@@ -486,13 +494,10 @@ static int forward_impl(const pg_model_cfg* cfg, const pg_params* p, int dtype, 
     // QKV projection (BertSelfAttention.query/key/value as one [3H,H] matrix)
     CK(g.run(s.x, true, H, pv.w(pv.lo(l, PG_L_WQ)), true, H, s.qkv, dtype, 3 * H, T, 3 * H, H, 1.f, 0.f,
              pv.m(pv.lo(l, PG_L_BQ))));
-    if (seq_off) {
-      CK(pg_attention_fwd_packed(dtype, s.qkv, mask, s.ctx, seq_off, B, S, d.nh, 3 * H, H, st));
-    } else if (!stash && fused && rag.on()) {
-      CK(pg_attention_fwd_packed(dtype, s.qkv, mask, s.ctx, rag.off, B, S, d.nh, 3 * H, H, st));
-    } else if (!stash && fused) {
+    if (seq_off || (!stash && fused)) {
       // nothing is kept for a backward: fused attention, no score matrix in HBM
-      CK(pg_attention_fwd(dtype, s.qkv, mask, s.ctx, B, S, d.nh, 3 * H, H, st));
+      CK(pg_attention_fwd_keys(dtype, s.qkv, mask, s.ctx, inf_off, B, S, d.nh, 3 * H, H, keys ? w.key_idx : nullptr,
+                               keys ? w.key_cnt : nullptr, st));
     } else if (fused && rag.on()) {
       CK(pg_attention_fwd_p_ragged(dtype, s.qkv, mask, s.ss, s.ctx, rag.off, B, S, 0, d.nh, 3 * H, H, st));
     } else if (fused) {

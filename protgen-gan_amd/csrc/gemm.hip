@@ -1226,6 +1226,7 @@ extern int pg_internal_colsum_chunks;
 extern int pg_internal_colsum_waves;
 extern int pg_internal_dw_depth;
 extern int pg_internal_round_mask;
+extern int pg_internal_visible_keys;
 extern int pg_internal_fused_dgelu_save;
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
@@ -1240,6 +1241,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 15) { pg_internal_fused_dgelu_save = value != 0; return PG_OK; }
   if (key == 16) { if (value < 0) return PG_ERR_ARG; g_gemm_deep_max_blocks = value; return PG_OK; }
   if (key == 14) { if (value < 1) return PG_ERR_ARG; g_gemm_wide_min_tiles = value; return PG_OK; }
+  if (key == 20) { pg_internal_visible_keys = value ? 1 : 0; return PG_OK; }
   if (key == 18) { if (value < 0 || value > 63) return PG_ERR_ARG; pg_internal_round_mask = value; return PG_OK; }
   if (key == 13) { if (value < 0 || value > 4) return PG_ERR_ARG; pg_internal_dw_depth = value; return PG_OK; }
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }

@@ -258,6 +258,25 @@ def attention_fwd_packed(qkv, mask, seq_off, max_len, heads):
     return ctx
 
 
+def attention_fwd_visible(qkv, mask, heads, B=None, S=None, seq_off=None, max_len=None):
+    """attention_fwd / attention_fwd_packed walking only the keys whose mask is 1 (pg_attention_key_lists +
+    pg_attention_fwd_keys).  Rectangle: pass B, S; packed rows: pass seq_off, max_len.  Returns (ctx, key_cnt)."""
+    packed = seq_off is not None
+    n = seq_off.numel() - 1 if packed else B
+    width = max_len if packed else S
+    T = qkv.shape[0]
+    idx = torch.empty(T, dtype=torch.int32, device=qkv.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=qkv.device)
+    so = seq_off.data_ptr() if packed else None
+    check(lib.pg_attention_key_lists(mask.data_ptr(), so, n, width, idx.data_ptr(), cnt.data_ptr(), stream()),
+          "pg_attention_key_lists")
+    ctx = torch.empty(T, heads * 64, dtype=qkv.dtype, device=qkv.device)
+    check(lib.pg_attention_fwd_keys(dt_code(qkv.dtype), qkv.data_ptr(), mask.data_ptr(), ctx.data_ptr(), so, n, width, heads,
+                                    qkv.stride(0), ctx.stride(0), idx.data_ptr(), cnt.data_ptr(), stream()),
+          "pg_attention_fwd_keys")
+    return ctx, cnt
+
+
 def attention_bwd_dq(qkv, P, ctx, dctx, B, S, heads):
     """First half of the attention backward over stored P: returns (dS [B*heads,S,ld], dq [B*S,H])."""
     H = heads * 64

@@ -529,6 +529,52 @@ def test_fused_attention_forward_packed_rows(pg):
     assert bool((ctx[T:].float() == canary).all()) and bool((ctx[:T].float() != canary).all())
 
 
+def test_fused_attention_forward_visible_keys(pg):
+    """The forward over the visible keys only (key lists built on the device) against eager attention in fp64 with the
+    additive mask: sparse masks (2 visible keys of 500: the first fill iteration), dense ones, a fully visible
+    sequence, a sequence with NO visible key (walked whole: uniform weights, as the reference's softmax gives) and a
+    mask with a value that is neither 0 nor 1 (walked whole under the additive mask); packed rows and a rectangle."""
+    g = torch.Generator().manual_seed(91)
+    nh = 2
+    H = nh * 64
+    lens = [500, 333, 64, 130, 7, 200, 97]
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    T = off[-1]
+    qkv = rnd(T, 3 * H, dtype=torch.bfloat16, gen=g)
+    qkv[:, :H] *= 2.0
+    mask = (torch.rand(T, generator=g) > 0.5).float()
+    mask[off[0]:off[1]] = 0.0
+    mask[off[0]] = 1.0
+    mask[off[0] + 417] = 1.0            # two visible keys of 500
+    mask[off[2]:off[3]] = 1.0           # fully visible
+    mask[off[3]:off[4]] = 0.0           # nothing visible
+    mask[off[5] + 3] = 0.5              # not a 0/1 mask
+    ref = torch.empty(T, H, dtype=torch.float64)
+    for a, b in zip(off, off[1:]):
+        q, k, v = (qkv[a:b, i * H:(i + 1) * H].double().view(b - a, nh, 64).transpose(0, 1) for i in range(3))
+        sc = q @ k.transpose(1, 2) * 0.125 + O.extended_mask(mask[a:b].view(1, -1), torch.float64).view(1, 1, -1)
+        ref[a:b] = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(b - a, H)
+    so = torch.tensor(off, dtype=torch.int32, device=DEV)
+    out, cnt = pg.ops.attention_fwd_visible(qkv.to(torch.bfloat16).to(DEV), mask.to(DEV), nh, seq_off=so, max_len=max(lens))
+    want = [int(mask[a:b].sum()) for a, b in zip(off, off[1:])]
+    want[3] = -1
+    want[5] = -1
+    assert cnt.tolist() == want
+    close(out, ref, torch.bfloat16)
+    # rectangle: 3 x 200
+    B, S = 3, 200
+    qkv2 = rnd(B * S, 3 * H, dtype=torch.bfloat16, gen=g)
+    m2 = (torch.rand(B, S, generator=g) > 0.7).float()
+    m2[:, 0] = 1.0
+    q, k, v = (qkv2[:, i * H:(i + 1) * H].double().view(B, S, nh, 64).transpose(1, 2) for i in range(3))
+    ref2 = (torch.softmax(q @ k.transpose(2, 3) * 0.125 + O.extended_mask(m2, torch.float64), -1) @ v).transpose(1, 2).reshape(B * S, H)
+    out2, cnt2 = pg.ops.attention_fwd_visible(qkv2.to(torch.bfloat16).to(DEV), m2.to(DEV).contiguous(), nh, B=B, S=S)
+    assert cnt2.tolist() == [int(x) for x in m2.sum(1)]
+    close(out2, ref2, torch.bfloat16)
+
+
 def test_embed_ln_packed_positions(pg):
     """Embedding + LayerNorm with explicit positions equals the rectangular kernel on the same (id, position) pairs."""
     from protgen_gan_amd._lib import check, lib
