@@ -227,13 +227,17 @@ def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequ
 
 
 def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask_real, fake, fake_mask, hp: GanHyper,
-                               grad_sync, alpha, ragged=False, real_lengths=None, fake_lengths=None) -> torch.Tensor:
+                               grad_sync, alpha, ragged=False, real_lengths=None, fake_lengths=None,
+                               train_encoder=True) -> Optional[torch.Tensor]:
     """The critic update with ONE encoder forward over 3B sequences: the gradient-penalty interpolates
     (loss.py:22-66) and the real and fake rows (fully_masked_train.py:321-323) use the same weights, and at
     B = 8 a forward over 4096 or 8192 token rows runs at little more than half the rate of one over 12 288.
     Everything after the forward is what `compute_gradient_penalty` + `critic(...)` + `c_loss.backward()` do,
     issued by hand on views of the shared stash: input-gradient pass and penalty on the first B sequences,
-    score backward on the other 2B, tangent and second-order passes on the first B."""
+    score backward on the other 2B, tangent and second-order passes on the first B.
+
+    `train_encoder=False` (the trainers' first epoch: encoder frozen, the head learns) exists in the ragged form
+    only; None is returned when that form does not apply and nothing has been done."""
     m, head = critic.protbert, critic.classifier
     B, S = real.shape
     H = m.config.hidden_size
@@ -242,11 +246,13 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     st = ops.stream()
     dev = real.device
     lam = float(hp.lambda_gp)
+    rmask = attn_mask_real.to(dev)
+    if not train_encoder and not (ragged and ONE_BACKWARD_DEFAULT and S % 8 == 0):
+        return None
     critic_optimizer.zero_grad()
     if alpha is None:
         alpha = torch.rand(B, 1, 1)
     alpha = alpha.to(device=dev, dtype=torch.float32).contiguous().view(B)
-    rmask = attn_mask_real.to(dev)
     joint = (rmask.bool() & fake_mask.bool()).to(torch.float32)
     if ragged and ONE_BACKWARD_DEFAULT and S % 8 == 0:
         # columns each row needs: up to the last one its mask shows (bounds given by the caller, or read back)
@@ -254,10 +260,10 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
         ef = [min(S, int(v)) for v in fake_lengths] if fake_lengths is not None else extents(fake_mask)
         lens_j = plan_lengths([min(a, b) for a, b in zip(er, ef)], S)
         lens_rf = plan_lengths(er + ef, S, floor=lens_j + lens_j)
-        if sum(lens_j) + sum(lens_rf) < 3 * B * S:
+        if sum(lens_j) + sum(lens_rf) < 3 * B * S or not train_encoder:
             return _critic_update_ragged(critic, critic_optimizer, real, rmask.to(torch.float32), fake,
                                          fake_mask.to(torch.float32), joint, lens_j, lens_rf[:B], lens_rf[B:], hp, grad_sync,
-                                         alpha)
+                                         alpha, train_encoder)
     mask3 = torch.cat([joint, rmask.to(torch.float32), fake_mask.to(torch.float32)], dim=0).contiguous()
 
     # embeddings of both batches straight into their rows of the 3B input, interpolates into the first B
@@ -336,11 +342,16 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
 
 
 def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, fake_mask, joint, lens_j, lens_r, lens_f,
-                          hp: GanHyper, grad_sync, alpha) -> torch.Tensor:
+                          hp: GanHyper, grad_sync, alpha, train_encoder=True) -> torch.Tensor:
     """_critic_update_one_forward over ragged rows: sequence b of the interpolates, of the real and of the fake
     batch runs on its lens_j[b] / lens_r[b] / lens_f[b] leading columns (lens_j[b] <= both others), all 3B
     sequences laid back to back.  Columns left out are hidden by the masks in every pass of the reference
-    (loss.py:41-66, models.py:87-93) and get zero gradient there; here they are not computed."""
+    (loss.py:41-66, models.py:87-93) and get zero gradient there; here they are not computed.
+
+    `train_encoder=False`: the encoder is frozen and only the head takes gradients (fully_masked_train.py:119-136).
+    The penalty then needs the input gradient of the interpolates and the tangent pass through the encoder, but
+    no parameter gradient of it: one first-order backward over the first B sequences without weight gradients,
+    no second-order pass, no embedding backward."""
     m, head = critic.protbert, critic.classifier
     B, S = real.shape
     H = m.config.hidden_size
@@ -361,7 +372,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
 
     # embeddings of the real and fake rows straight into their rows of the input, interpolates in front
     X = torch.empty(T3, H, dtype=cd, device=dev)
-    sums = torch.empty(Trf, H, dtype=cd, device=dev)
+    sums = torch.empty(Trf, H, dtype=cd, device=dev) if train_encoder else None
     m._embed_packed(ids_rf, rgRF.pos, X[Tj:], sums)
     check(lib.pg_interpolate_ragged(dt, X[Tj:].data_ptr(), X[Tj:].data_ptr(), alpha.data_ptr(), X.data_ptr(),
                                     rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H, st),
@@ -373,22 +384,31 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
     check(lib.pg_head_forward(dt, cls.data_ptr(), H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
                               hstash.data_ptr(), st), "pg_head_forward")
-    m.store.begin_accumulate()
+    if train_encoder:
+        m.store.begin_accumulate()
     head.store.begin_accumulate()
     ghead = head.store.grad
     w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
     norms = torch.empty(B, dtype=torch.float32, device=dev)
     gp = torch.empty((), dtype=torch.float32, device=dev)
-    # one first-order backward over the 3B sequences (see _critic_update_one_forward)
     dcls = torch.empty(3 * B, H, dtype=cd, device=dev)
     check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dcls.data_ptr(), H, st),
           "pg_head_backward")
-    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
-                               ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
-    dh3 = torch.zeros(T3, H, dtype=cd, device=dev).index_copy_(0, rg3.cls_rows, dcls)
-    adj = m._new_stash(3 * B, S, T3)
-    dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B, rgd=rg3.desc(), T=T3)
-    g, dx2 = dx3[:Tj], dx3[Tj:]
+    rgd = rg3.desc(0, B, stash_T=T3, adj_T=T3)
+    if train_encoder:
+        # one first-order backward over the 3B sequences (see _critic_update_one_forward)
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                                   ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
+        dh3 = torch.zeros(T3, H, dtype=cd, device=dev).index_copy_(0, rg3.cls_rows, dcls)
+        adj = m._new_stash(3 * B, S, T3)
+        dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B, rgd=rg3.desc(), T=T3)
+        g, dx2 = dx3[:Tj], dx3[Tj:]
+    else:
+        # the head's gradient from the real and fake scores; the encoder only hands the interpolates' input gradient back
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                                   ghead.data_ptr(), None, H, st), "pg_head_backward")
+        dhj = torch.zeros(Tj, H, dtype=cd, device=dev).index_copy_(0, rgJ.cls_rows, dcls[:B])
+        g = m._encode_backward(stash, dhj, B, S, param_grads=False, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
     check(lib.pg_gp_norms_ragged(dt, g.data_ptr(), mask3.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H, norms.data_ptr(),
                                  gp.data_ptr(), st), "pg_gp_norms_ragged")
     c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
@@ -398,12 +418,16 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     check(lib.pg_gp_direction_ragged(dt, g.data_ptr(), mask3.data_ptr(), norms.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H,
                                      scale.data_ptr(), v.data_ptr(), None, st), "pg_gp_direction_ragged")
     tan = m._new_stash(B, S, Tj)
-    rgd = rg3.desc(0, B, stash_T=T3, adj_T=T3)
     hdot = m._encode_jvp(stash, v, B, S, tan, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
     hdot_cls = hdot.index_select(0, rgJ.cls_rows)
     tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
     check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot_cls.data_ptr(), H, B, H, 1.0,
                                ghead.data_ptr(), tstash.data_ptr(), None, st), "pg_head_jvp_grad")
+    if not train_encoder:
+        if grad_sync is not None:
+            grad_sync()
+        critic_optimizer.step()
+        return c_loss.detach()
     xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0, adj_rows=3 * B, rgd=rgd, T=Tj)
     # the interpolates' input gradient joins the real and fake rows' own (loss.py:29), then one embedding backward
     check(lib.pg_interpolate_bwd_ragged(dt, xbar.data_ptr(), alpha.data_ptr(), dx2.data_ptr(), dx2.data_ptr(),
@@ -434,7 +458,18 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
     read back once (one device-to-host copy per update)."""
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
-    trainable = critic.protbert.encoder_trainable() and critic.classifier[0].weight.requires_grad
+    head_trains = critic.classifier[0].weight.requires_grad
+    trainable = critic.protbert.encoder_trainable() and head_trains
+    # (the trainers' first epoch: every encoder parameter frozen, the head learns)
+    head_only = head_trains and not any(p.requires_grad for p in critic.protbert.parameters())
+    if one_forward is None and head_only and ONE_FORWARD_DEFAULT and (ragged if ragged is not None else RAGGED_DEFAULT):
+        real = critic.protbert._check_ids(real_data, values=False)
+        fk = critic.protbert._check_ids(fake, values=False)
+        if real.shape == fk.shape:
+            done = _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha,
+                                              True, real_lengths, fake_lengths, train_encoder=False)
+            if done is not None:
+                return done
     if one_forward is None:
         one_forward = trainable and ONE_FORWARD_DEFAULT
     if one_forward:

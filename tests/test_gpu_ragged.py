@@ -249,3 +249,43 @@ def test_ragged_matches_rectangular_bf16(pg):
     worst = max((float((out[True][1][n] - ref).norm() / (ref.norm() + 1e-12)), n) for n, ref in out[False][1].items()
                 if "key.bias" not in n)
     assert worst[0] < 2e-2, worst
+
+
+@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 2e-4, 2e-3), (BF, 2e-2, 6e-2)])
+def test_ragged_frozen_encoder_update_vs_oracle(pg, dtype, ltol, gtol):
+    """The trainers' first epoch (freeze_protbert: encoder frozen, the head learns, fully_masked_train.py:119-136) on
+    ragged rows: loss and the head's gradients against the oracle with train_encoder=False; the encoder's parameters
+    keep `grad is None`."""
+    from protgen_gan_amd import train as T
+    c, P, PC, Ch, _, critic = build(pg, "tiny", dtype)
+    T.freeze_protbert(critic, True)
+    B, S = 4, 64
+    ext_r, ext_f = [64, 30, 17, 41], [50, 64, 9, 40]
+    real, fake, rm, fm = _padded_batches(B, S, ext_r, ext_f, 84)
+    alpha = torch.rand(B, 1, 1, generator=torch.Generator().manual_seed(5))
+    loss, gp, rs, fs, grads = O.critic_step_grads(PC, Ch, c, real, fake, rm, fm, alpha, 5.0, train_encoder=False)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    calls = []
+    orig = T._critic_update_ragged
+    T._critic_update_ragged = lambda *a, **k: (calls.append(a[-1] if not k else k.get("train_encoder", a[-1])), orig(*a, **k))[1]
+    try:
+        l_h = T.critic_update(critic, _NoStep(critic), d(real), d(rm), d(fake), T.GanHyper(lambda_gp=5.0), alpha=alpha)
+    finally:
+        T._critic_update_ragged = orig
+    torch.cuda.synchronize()
+    assert calls == [False], "the frozen ragged path did not run"
+    rel_close(l_h.item(), loss.numpy(), ltol, "loss")
+    named = dict(critic.named_parameters())
+    assert {n for n, p in named.items() if p.grad is not None} == set(grads.keys())
+    assert all(n.startswith("classifier.") for n in grads)
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    if dtype == torch.float32:  # (bf16: the real and fake terms nearly cancel and a hidden state rounded to bf16 can flip
+        for n, gref in grads.items():  # a gate of the head, so a per-tensor bound against fp32 says nothing; see below)
+            rel_close(named[n].grad.cpu().numpy(), gref.numpy(), gtol, f"grad {n}", atol=1e-6 * gmax)
+    # and equal to the call-by-call form through autograd (rectangular passes, the same precision)
+    ref = {n: p.grad.clone() for n, p in named.items() if p.grad is not None}
+    l2 = T.critic_update(critic, _NoStep(critic), d(real), d(rm), d(fake), T.GanHyper(lambda_gp=5.0), alpha=alpha, ragged=False)
+    torch.cuda.synchronize()
+    assert abs(float(l2) - float(l_h)) <= ltol * abs(float(l_h)) + 1e-6
+    for n, gref in ref.items():
+        assert rel_l2(named[n].grad.cpu().numpy(), gref.cpu().numpy()) < (1e-4 if dtype == torch.float32 else 5e-2), n
