@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libprotgen_hip.so")
+# (PG_LIB: another build of the same library, for A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get("PG_LIB") or os.path.join(HERE, "libprotgen_hip.so")
 
 PG_F32, PG_BF16 = 0, 1
 PG_ACT_NONE, PG_ACT_GELU, PG_ACT_MUL_DGELU = 0, 1, 2

@@ -196,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     float* ml = reinterpret_cast<float*>(smem + 4 * TILE);
     int* il = reinterpret_cast<int*>(smem + 4 * TILE + 2 * MAX_S);
     const int s_pad = ((Sk + KT - 1) / KT) * KT;
-    const int last = kidx ? kidx[Sk - 1] : Sk - 1;
     for (int k = threadIdx.x; k < s_pad; k += 256) {
       float a = 0.f;
       if (k >= Sk) a = -INFINITY;                              // beyond the walk: weight exactly 0
       else if (!kidx && mrow) a = (1.0f - mrow[k]) * -FLT_MAX;  // HF additive mask, finfo(float32).min
       ml[k] = a;
-      il[k] = k < Sk ? (kidx ? kidx[k] : k) : last;
+      const int kc = k < Sk ? k : Sk - 1;                       // (past the walk: any valid row, its weight is 0)
+      il[k] = kidx ? kidx[kc] : kc;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
