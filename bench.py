@@ -248,7 +248,7 @@ def main():
         out["generate"] = time_generate(pg, generator, pool, rank, world, dev, batches=args.generate_batches)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, pg, dev)
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
@@ -298,7 +298,7 @@ def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, pg=None, dev=None):
     """The CPU oracle (a plain-PyTorch fp32 restatement of the reference path) timed on this
     box's host cores on a bounded sample: one fill iteration and one critic update (GP double
     backward + real + fake + backward + AdamW) at batch 2, len 512, full-size ProtBERT (about 10 s
@@ -321,8 +321,9 @@ def cpu_baseline(args):
     real = torch.randint(5, 25, (Bs, S), generator=g)
     fake = torch.randint(5, 25, (Bs, S), generator=g)
     ones = torch.ones(Bs, S, dtype=torch.long)
+    alpha = torch.rand(Bs, 1, 1, generator=g)
     t0 = time.perf_counter()
-    loss, gp, rs, fs, grads = O.critic_step_grads(P, C, c, real, fake, ones, ones, torch.rand(Bs, 1, 1, generator=g), args.lambda_gp)
+    loss, gp, rs, fs, grads = O.critic_step_grads(P, C, c, real, fake, ones, ones, alpha, args.lambda_gp)
     k = "protbert.bert.encoder.layer.0.output.dense.weight"
     p, gr = P[k[len("protbert."):]].clone(), grads[k]
     t1 = time.perf_counter()
@@ -331,7 +332,28 @@ def cpu_baseline(args):
     t_bwd = t1 - t0                      # Bs sequences through GP + real + fake + backward
     t_critic = t_bwd / Bs + t_adam / args.batch  # per sequence of a batch-`batch` update (one AdamW step per update)
     t_step = args.n_critic * (args.batch * t_critic + 10 * args.batch * t_fill) + (10 * args.gen_batch * t_fill + args.gen_batch * t_critic / 4)
-    return {"value": round(1.0 / t_step, 6), "unit": "GAN steps/s", "cores": cores, "kind": "port",
+    probe = None
+    if pg is not None:
+        # the same critic update (same weights, inputs, alpha) on the engine in the benchmark's precision: the
+        # oracle as the checker of what was timed above (loss, penalty and scores; gradients are the tests' job)
+        from protgen_gan_amd import train as pgt
+        dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        cfg = pg.ProtBertConfig(num_hidden_layers=args.layers, max_position_embeddings=args.seq)
+        critic = pg.Critic(pg.ProtBertForMaskedLM.from_params(cfg, P, device=dev, compute_dtype=dt))
+        critic.classifier.load_state_dict(C)
+        d = lambda t: t.to(dev)  # noqa: E731
+        gp_h = pg.compute_gradient_penalty(critic, d(real), d(fake), d(ones), d(ones), dev, alpha=alpha)
+        with torch.no_grad():
+            rs_h, fs_h = critic(d(real), attention_mask=d(ones)), critic(d(fake), attention_mask=d(ones))
+        l_h = pg.critic_loss(rs_h, fs_h, gp_h, args.lambda_gp)
+        sc = torch.cat([rs, fs]).detach()
+        sc_h = torch.cat([rs_h, fs_h]).detach().cpu()
+        probe = {"what": f"one critic update B={Bs} S={S}, {args.layers} layers, engine ({args.dtype}) against the fp32 CPU oracle, same weights and draws",
+                 "c_loss_oracle": float(loss.detach()), "c_loss_engine": float(l_h.detach()), "gp_oracle": float(gp.detach()),
+                 "gp_engine": float(gp_h.detach()),
+                 "scores_max_abs_err": float((sc_h - sc).abs().max()), "scores_max_abs": float(sc.abs().max())}
+        del critic
+    return {"value": round(1.0 / t_step, 6), "unit": "GAN steps/s", "cores": cores, "kind": "port", "parity_probe": probe,
             "sample": (f"oracle/protbert_cpu.py fp32 on {cores} host threads: 1 fill iteration B={Bs} S={S} ({t_fill:.2f} s/seq) + 1 critic "
                        f"update B={Bs} S={S} incl. GP double backward ({t_bwd:.2f} s) and AdamW ({t_adam:.2f} s/step); per sequence "
                        f"{t_critic:.2f} s; GAN step composed as "

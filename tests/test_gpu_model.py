@@ -728,8 +728,10 @@ def test_full_size_critic_step_bf16_vs_oracle(pg, full_params):
     typical = norms[len(norms) // 2]
     sized = [n for n in picked if float(grads[n].norm()) > 0.05 * typical]
     assert len(sized) >= len(picked) - 4
-    worst = max((rel_l2(named[n].grad.cpu().numpy(), grads[n].numpy()), n) for n in sized)
-    assert worst[0] < 0.12, worst
+    dist = sorted((rel_l2(named[n].grad.cpu().numpy(), grads[n].numpy()), n) for n in sized)
+    worst, median = dist[-1], dist[len(dist) // 2]
+    print("full size bf16, gates open: median", median, "worst", worst)
+    assert worst[0] < 0.05 and median[0] < 0.04, (median, worst)  # measured 2.4 % and 1.9 %
 
 
 def test_full_size_stacked_fill_bf16(pg, full_params):
