@@ -113,6 +113,16 @@ template <> struct VecIO<bf16_t, 8> {
     v.w = (uint32_t)f32_to_bf16_bits(o[6]) | ((uint32_t)f32_to_bf16_bits(o[7]) << 16);
     *reinterpret_cast<uint4*>(p) = v;
   }
+  // streaming store: the line is not kept in the caches on its way out
+  static __device__ __forceinline__ void store_nt(bf16_t* p, const float* o) {
+    typedef __attribute__((ext_vector_type(4))) unsigned nt_u4;
+    nt_u4 v;
+    v[0] = (uint32_t)f32_to_bf16_bits(o[0]) | ((uint32_t)f32_to_bf16_bits(o[1]) << 16);
+    v[1] = (uint32_t)f32_to_bf16_bits(o[2]) | ((uint32_t)f32_to_bf16_bits(o[3]) << 16);
+    v[2] = (uint32_t)f32_to_bf16_bits(o[4]) | ((uint32_t)f32_to_bf16_bits(o[5]) << 16);
+    v[3] = (uint32_t)f32_to_bf16_bits(o[6]) | ((uint32_t)f32_to_bf16_bits(o[7]) << 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_u4*>(p));
+  }
 };
 template <> struct VecIO<bf16_t, 4> {
   static __device__ __forceinline__ void load(const bf16_t* p, float* o) {

@@ -79,9 +79,17 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull, narrow):
     assert torch.equal(out.cpu().double(), ref)
 
 
+@pytest.fixture(params=[1, 0], ids=["ring", "two_stage"])
+def ring(request, pg):
+    """Both 256x256-tile kernels for k-major x k-major products: the two-stage one (default) and the five-slot ring."""
+    pg._lib.lib.pg_tune(21, request.param)
+    yield request.param
+    pg._lib.lib.pg_tune(21, 0)
+
+
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("shape", [(520, 776, 192), (256, 256, 64), (264, 520, 320)])
-def test_gemm_wide_tile_exact(pg, ak, bk, shape):
+@pytest.mark.parametrize("shape", [(520, 776, 192), (256, 256, 64), (264, 520, 320), (304, 264, 1088), (256, 512, 128)])
+def test_gemm_wide_tile_exact(pg, ring, ak, bk, shape):
     """The 256x256-tile bf16 kernel (forced; normally only large-N products take it): exact
     integers over several tiles with ragged M and N edges, all four operand layouts, and both
     output types."""
@@ -106,7 +114,7 @@ def test_gemm_wide_tile_exact(pg, ak, bk, shape):
     close(out16, ref / 64, torch.bfloat16)
 
 
-def test_gemm_wide_tile_epilogues(pg):
+def test_gemm_wide_tile_epilogues(pg, ring):
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(12)
     M, N, Kd = 520, 512, 256
@@ -221,7 +229,7 @@ def test_gemm_two_reduction_segments(pg, dtype, T, T2):
         close(out, dY[:, :56].double().T @ X[:, :56].double() + dYb[:, :56].double().T @ Xb[:, :56].double() + 1.0, dtype)
 
 
-def test_gemm_wide_tile_split_last_round(pg):
+def test_gemm_wide_tile_split_last_round(pg, ring):
     """A large-N product whose 256x256 tiles fill the CUs once plus a few: the rows past the last
     full round of tiles go to a second launch.  Exact integers plus every row-offset epilogue
     operand (residual, stored pre-activation) across the seam."""
@@ -248,7 +256,7 @@ def test_gemm_wide_tile_split_last_round(pg):
     close(out, K_gelu(ref / 64 + bias.double()), bf)
 
 
-def test_gemm_split_last_round_two_segments(pg):
+def test_gemm_split_last_round_two_segments(pg, ring):
     """The same split with a second reduction segment and a k-major A: the rows that go to the second
     launch must take the same rows of A2.  Exact integers against two plain products."""
     g = torch.Generator().manual_seed(43)
