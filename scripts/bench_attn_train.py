@@ -17,6 +17,9 @@ pg = pgload.load()
 from protgen_gan_amd._lib import lib
 from protgen_gan_amd.ragged import Ragged
 
+for kv in os.environ.get("PG_TUNE", "").split(","):  # e.g. PG_TUNE=23=0
+    if kv:
+        lib.pg_tune(*[int(x) for x in kv.split("=")])
 DEV, BF = "cuda", torch.bfloat16
 heads, S = 16, 512
 H = heads * 64
