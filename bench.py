@@ -159,6 +159,7 @@ def main():
             print(f"[rank {rank}] warm-up step {i} done", file=sys.stderr, flush=True)
     fence()
     generator.fill_shapes.clear()
+    generator.fill_widths.clear()
     lib.pg_profile_begin(args.profile_sample)
     t0 = time.perf_counter()
     last = None
@@ -266,6 +267,7 @@ def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1
     if world > 1:
         torch.distributed.barrier()
     generator.fill_shapes.clear()
+    generator.fill_widths.clear()
     t0 = time.perf_counter()
     seqs = gen_py.generate_full_mode_sequences(generator, tok, n, pool, batch_size=bs, device=str(dev), rng_seed=42 + rank)
     torch.cuda.synchronize()
@@ -276,7 +278,9 @@ def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1
         t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
+    # algorithmic FLOPs: every row at its own length L + 2 (batch padding to the longest row is not work the path asks for)
+    flops = sum(B * S * f_gen_tok(S) if w is None else sum(x * f_gen_tok(x) for x in w)
+                for (B, S), w in zip(generator.fill_shapes, generator.fill_widths))
     return {"value": round(world * n / dt, 3), "unit": "sequences/s", "sequences_per_rank": n, "batch": bs, "seconds": round(dt, 4),
             "mean_len": round(sum(len(s) for s in seqs) / len(seqs), 1), "step_mfma_frac": round(flops / dt / MFMA_PEAK_BF16, 4),
             "workload": "configs[3]-style mass generation (generate.py full mode), lengths uniform %d..%d, 10 fill iterations"

@@ -926,7 +926,7 @@ int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after th
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
 int g_gemm_small_grid = 0;  // most 128x128 tiles of an unbatched product that takes 128x64 tiles instead (pg_tune key 19; off)
-int g_gemm_split_tail = 1;  // 256-tile products: rows of a sparse last round go to a second launch
+int g_gemm_split_tail = 50;  // 256-tile products: the rows of a last round less than this many per cent full go to a second launch (0 = never)
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
 int g_gemm_wide_min_tiles = 160;  // fewest 256x256 tiles at which a narrow-N (512 <= N < 2048) product takes the 256x256 kernel
@@ -967,7 +967,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 12) { if (value < 1) return PG_ERR_ARG; pg_internal_colsum_chunks = value; return PG_OK; }
   if (key == 17) { if (value != 4 && value != 16) return PG_ERR_ARG; pg_internal_colsum_waves = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
-  if (key == 9) { g_gemm_split_tail = value; return PG_OK; }
+  if (key == 9) { if (value < 0 || value > 100) return PG_ERR_ARG; g_gemm_split_tail = value == 1 ? 50 : value; return PG_OK; }
   if (key == 19) { if (value < 0) return PG_ERR_ARG; g_gemm_small_grid = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   if (key == 22) { if (value < 0) return PG_ERR_ARG; g_gemm_nt_store_mb = value; return PG_OK; }
@@ -1031,14 +1031,15 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
     return pg_gemm(&one, stream);
   }
   if (wide && g_gemm_wide == 1 && g_gemm_split_tail && d->batch == 1 && d->a_kmajor) {
-    // One 256x256 tile per CU and round: when the last round would be under 30 % full, the rows
-    // beyond the last full round go to a second launch (which takes the 128x128 kernel) instead
-    // of costing a whole round.
+    // One 256x256 tile per CU and round: when the last round would be less than half full (pg_tune key 9), the
+    // rows beyond the last full round go to a second launch (which takes the 128x128 kernel) instead of costing
+    // a whole round.  (Measured at thresholds 30 / 40 / 50 / 60 %: mass generation at batch 64, whose N = 1024
+    // products have 1.25 - 1.5 rounds of tiles, 240 / 246 / 248 / 249 sequences/s; the GAN step unchanged.)
     const int cus = device_cus();
     const long tiles = tiles256(d), full = tiles / cus;
     const int gxw = (d->N + 255) / 256;
     const long rows1 = full * cus / gxw * 256;  // whole tile rows inside the full rounds
-    if (full >= 1 && tiles % cus != 0 && (tiles % cus) * 10 < 3 * (long)cus && rows1 > 0 && rows1 < d->M) {
+    if (full >= 1 && tiles % cus != 0 && (tiles % cus) * 100 < (long)g_gemm_split_tail * cus && rows1 > 0 && rows1 < d->M) {
       const int esz = 2, csz = d->c_dtype == PG_F32 ? 4 : 2;
       pg_gemm_desc top = *d, rest = *d;
       top.M = (int)rows1;

@@ -45,6 +45,7 @@ class Generator(nn.Module):
         self.last_counts = None  # int32 [B,2] on device: (committed, masks left) of the last generate()
         self.fill_calls = 0      # bookkeeping for throughput reports: calls and their (B, S)
         self.fill_shapes = []
+        self.fill_widths = []    # per call: None (every row at full width) or the rows' own widths of a packed pass
 
     def forward(self, input_ids, attention_mask=None):
         outputs = self.protbert(input_ids=input_ids, attention_mask=attention_mask)
@@ -52,15 +53,17 @@ class Generator(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask=None, temperature=1.0, keep_percent=0.1, current_rate=None,
-                 noise=None):
+                 noise=None, packing: "RowPacking | None" = None):
         """One iterative-fill step; mutates and returns `input_ids` (models.py:18-64).
 
         Every position of every row is sampled (pad and already-filled ones too), so the
         Exp(1) noise has shape [B*S, V] exactly like the draw `torch.multinomial` makes; it
         is taken from the device's global generator unless `noise` is given (tests inject
-        the reference's draw).  Ties in the top-k are broken towards the lowest index."""
+        the reference's draw).  Ties in the top-k are broken towards the lowest index.
+
+        `packing` (not in the reference's signature; bf16): see generate_groups."""
         return self._fill_step(input_ids, attention_mask, [(0, input_ids.shape[0], float(temperature))], keep_percent,
-                               current_rate, noise)
+                               current_rate, noise, packing)
 
     @torch.no_grad()
     def generate_groups(self, input_ids, attention_mask, groups, keep_percent=0.1, current_rate=None, noise=None,
@@ -111,6 +114,7 @@ class Generator(nn.Module):
         self.fill_calls += 1
         if len(self.fill_shapes) < 100000:
             self.fill_shapes.append((B, S))
+            self.fill_widths.append(None)
         if not inplace:
             input_ids.copy_(ids)
         return input_ids
@@ -147,6 +151,7 @@ class Generator(nn.Module):
         self.fill_calls += 1
         if len(self.fill_shapes) < 100000:
             self.fill_shapes.append((B, S))
+            self.fill_widths.append(pk.widths)
         if ids.data_ptr() != input_ids.data_ptr():
             input_ids.copy_(ids)
         return input_ids

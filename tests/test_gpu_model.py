@@ -576,6 +576,38 @@ def test_generate_py_loops_vs_reference(pg, golden_dir):
     assert seeded == G["seeded"].tolist()
 
 
+def test_generate_py_packs_rows_to_their_lengths_bf16(pg, monkeypatch):
+    """generate.py's loops in bf16 run every row on its own L + 2 columns (the columns behind are pads under
+    attention mask 0): same strings as the full-width pass when both consume the same noise, in both modes."""
+    c, P, _, _, gen, _ = build(pg, "mid", torch.bfloat16)
+    from protgen_gan_amd import generate as gen_py
+    tok = pg.ProtTokenizer()
+    packed_calls = []
+
+    class Replay(pg.Generator):
+        def generate(self, input_ids, **kw):
+            packed_calls.append(kw.get("packing") is not None)
+            n = torch.empty(input_ids.numel(), c.vocab_size).exponential_(1)
+            return super().generate(input_ids, noise=n, **kw)
+
+    rep = Replay(gen.protbert)
+    pool = [20, 37, 45, 51, 64, 90]
+    seeds = ["ACDEFGHIKLMNPQRSTVWY" * 3, "MKV" * 9, "GASTLIVNQ" * 5, "WYFHKRDE" * 4]
+    out = []
+    for packed in (True, False):
+        if not packed:
+            monkeypatch.setattr(gen_py, "_row_packing", lambda *a, **k: None)
+        packed_calls.clear()
+        torch.manual_seed(77)
+        full = gen_py.generate_full_mode_sequences(rep, tok, 9, pool, batch_size=4, device=DEV, rng_seed=5)
+        torch.manual_seed(78)
+        seeded = gen_py.generate_seeded_mode_sequences(rep, tok, 7, seeds, keep_init=0.2, batch_size=4, device=DEV, rng_seed=6)
+        assert any(packed_calls) == packed
+        out.append((full, seeded))
+    assert out[0] == out[1]
+    assert all(len(s) > 0 for s in out[0][0])
+
+
 def test_save_and_load_pretrained_roundtrip(pg, tmp_path):
     c, P, PC, C, gen, critic = build(pg, "tiny", torch.float32)
     d = str(tmp_path / "generator_bert")
