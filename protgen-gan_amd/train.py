@@ -500,11 +500,72 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
     return c_loss.detach()
 
 
-def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0) -> torch.Tensor:
+def _generator_scores_ragged(critic: Critic, fake, fake_mask, lens) -> torch.Tensor:
+    """`g_loss = -mean(critic(fake))` and its backward into the critic (fully_masked_train.py:349-351) with every
+    fake row on its lens[b] leading columns: the columns behind are pads under attention mask 0 (models.py:87-93),
+    which no kept row attends and whose own rows reach no score.  Same kernels as the critic update's real and fake
+    rows; gradients accumulate on top of what the critic's buffers hold, as autograd's would."""
+    m, head = critic.protbert, critic.classifier
+    B, S = fake.shape
+    H = m.config.hidden_size
+    cd = m.compute_dtype
+    dt = ops.dt_code(cd)
+    st = ops.stream()
+    dev = fake.device
+    train_encoder = m.encoder_trainable()
+    rg = Ragged(list(lens), S, dev)
+    T = rg.T
+    ids_p = rg.pack(fake).contiguous()
+    mask_p = rg.pack(fake_mask.to(torch.float32)).contiguous()
+    X = torch.empty(T, H, dtype=cd, device=dev)
+    sums = torch.empty(T, H, dtype=cd, device=dev) if train_encoder else None
+    m._embed_packed(ids_p, rg.pos, X, sums)
+    hidden, stash = m._encode_ragged(rg, x=X, mask_p=mask_p, want_stash=train_encoder)
+    del X
+    cls = hidden.index_select(0, rg.cls_rows)
+    scores = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    hstash = torch.empty(B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
+    check(lib.pg_head_forward(dt, cls.data_ptr(), H, head.store.master.data_ptr(), B, H, scores.data_ptr(), hstash.data_ptr(), st),
+          "pg_head_forward")
+    g_loss = generator_loss(scores)
+    head.store.begin_accumulate()
+    w = torch.full((B,), -1.0 / B, dtype=torch.float32, device=dev)  # d g_loss / d score
+    dcls = torch.empty(B, H, dtype=cd, device=dev) if train_encoder else None
+    check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), w.data_ptr(), B, H,
+                               head.store.grad.data_ptr(), ops.ptr(dcls), H, st), "pg_head_backward")
+    if train_encoder:
+        m.store.begin_accumulate()
+        dh = torch.zeros(T, H, dtype=cd, device=dev).index_copy_(0, rg.cls_rows, dcls)
+        dx = m._encode_backward(stash, dh, B, S, param_grads=True, rgd=rg.desc(), T=T)
+        m._embed_backward_packed(ids_p, rg.pos, sums, dx)
+    return g_loss
+
+
+def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0, fake_lengths=None,
+                     ragged: Optional[bool] = None) -> torch.Tensor:
     """fully_masked_train.py:335-352.  Token ids carry no gradient, so this back-propagates
     into the critic only and `gen_optimizer.step()` changes nothing — kept because the
-    reference does the same work."""
+    reference does the same work.
+
+    `ragged` (default on, when the critic's encoder and head both train): the fake rows run on their
+    leading columns up to the last one the mask `fake != PAD` shows (`fake_lengths`: host-side upper bounds of
+    that count, else the mask is read back once), as in critic_update; False = the call through autograd."""
     gen_optimizer.zero_grad()
+    m = critic.protbert
+    fake = fake_data.detach()
+    if ragged is None:
+        ragged = RAGGED_DEFAULT
+    S = fake.shape[1]
+    if (ragged and ONE_BACKWARD_DEFAULT and S % 8 == 0 and m.encoder_trainable()
+            and critic.classifier[0].weight.requires_grad):
+        fk = m._check_ids(fake, values=False)
+        fake_mask = (fk != pad_id).long()
+        ext = [min(S, int(v)) for v in fake_lengths] if fake_lengths is not None else extents(fake_mask)
+        lens = plan_lengths(ext, S)
+        if sum(lens) < fk.numel():
+            g_loss = _generator_scores_ragged(critic, fk, fake_mask, lens)
+            gen_optimizer.step()
+            return g_loss.detach()
     fake_scores = critic(fake_data, attention_mask=(fake_data != pad_id).long())
     g_loss = generator_loss(fake_scores)
     g_loss.backward()
@@ -624,7 +685,7 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
         g = generator_update_soft(generator, critic, gen_optimizer, tpl, visible.long(), temperature=temps[-1][0],
                                   critic_attention_mask=(tpl != 0).long(), grad_sync=gen_grad_sync)
     else:
-        g = generator_update(critic, gen_optimizer, fakes[-1])
+        g = generator_update(critic, gen_optimizer, fakes[-1], fake_lengths=lengths[-1])
     return c_sum / hp.n_critic, g
 
 
@@ -655,7 +716,7 @@ def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_
             g = generator_update_soft(generator, critic, gen_optimizer, tpl, (tpl != 0).long(), temperature=temperature,
                                       grad_sync=gen_grad_sync)
         else:
-            g = generator_update(critic, gen_optimizer, fakes[hp.n_critic])
+            g = generator_update(critic, gen_optimizer, fakes[hp.n_critic], fake_lengths=gen_batches[hp.n_critic].get("lengths"))
         return c_sum / hp.n_critic, g
     for batch, gb in zip(real_batches[:hp.n_critic], gen_batches[:hp.n_critic]):
         fake = generate_fakes_for_batch(generator, gb["input_ids"], hp)

@@ -289,3 +289,50 @@ def test_ragged_frozen_encoder_update_vs_oracle(pg, dtype, ltol, gtol):
     assert abs(float(l2) - float(l_h)) <= ltol * abs(float(l_h)) + 1e-6
     for n, gref in ref.items():
         assert rel_l2(named[n].grad.cpu().numpy(), gref.cpu().numpy()) < (1e-4 if dtype == torch.float32 else 5e-2), n
+
+
+@pytest.mark.parametrize("dtype,gtol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("host_lengths", [False, True])
+def test_ragged_generator_update_matches_autograd_form(pg, dtype, gtol, host_lengths):
+    """generator_update (g_loss = -mean critic(fake), backward into the critic) with the fake rows on their own
+    lengths against the call through autograd on the padded batch: same loss, same gradients, same `grad is None`
+    set, and gradients ADD to what the critic's buffers held (the reference does not clear them before this step)."""
+    from protgen_gan_amd import train as T
+
+    class GenOpt:
+        def zero_grad(self):
+            pass
+
+        def step(self):
+            pass
+
+    B, S = 4, 64
+    ext_f = [50, 64, 9, 40]
+    _, fake, _, _ = _padded_batches(B, S, [64] * B, ext_f, 83)
+    res = []
+    for ragged in (True, False):
+        c, P, PC, Ch, _, critic = build(pg, "tiny", dtype)
+        critic.zero_grad(set_to_none=True)
+        calls = []
+        orig = T._generator_scores_ragged
+        T._generator_scores_ragged = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            kw = dict(fake_lengths=ext_f) if host_lengths else {}
+            g1 = T.generator_update(critic, GenOpt(), fake.to(DEV), ragged=ragged, **kw)
+            g2 = T.generator_update(critic, GenOpt(), fake.to(DEV), ragged=ragged, **kw)  # accumulates
+        finally:
+            T._generator_scores_ragged = orig
+        assert bool(calls) == ragged
+        res.append((float(g1), float(g2), {n: (None if p.grad is None else p.grad.float().cpu().clone())
+                                            for n, p in critic.named_parameters()}))
+    (a1, a2, ga), (b1, b2, gb) = res
+    rel_close(a1, b1, 2e-4 if dtype == torch.float32 else 2e-2, "g_loss")
+    assert a1 == a2 and b1 == b2
+    assert {n for n, g in ga.items() if g is not None} == {n for n, g in gb.items() if g is not None}
+    for n, g in gb.items():
+        if g is None:
+            continue
+        if dtype == torch.float32:
+            rel_close(ga[n].numpy(), g.numpy(), gtol, f"grad {n}", atol=1e-7)
+        else:
+            assert rel_l2(ga[n], g) <= gtol or float(g.abs().max()) < 1e-6, (n, rel_l2(ga[n], g))
