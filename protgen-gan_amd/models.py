@@ -132,7 +132,9 @@ class Generator(nn.Module):
         hidden = m._encode_packed(ids.view(-1)[pk.idx], pk.pos, pk.seq_off, mask.view(-1)[pk.idx], B, S)
         logits = m.lm_logits(hidden.view(1, T, -1), ws_shape=(B, S)).view(T, V)
         if noise is None:
-            noise = torch.empty(T, V, dtype=torch.float32, device=ids.device).exponential_(1.0)
+            # the full-width pass's draw (every position of every row, models.py:24-27), of which the kept columns'
+            # part is used: the device generator ends in the same state with and without packing
+            noise = torch.empty(B * S, V, dtype=torch.float32, device=ids.device).exponential_(1.0)[pk.idx]
         else:
             noise = noise.to(device=ids.device, dtype=torch.float32).contiguous().view(B * S, V)[pk.idx]
         pred_p = torch.empty(T, dtype=torch.long, device=ids.device)

@@ -606,6 +606,17 @@ def test_generate_py_packs_rows_to_their_lengths_bf16(pg, monkeypatch):
         out.append((full, seeded))
     assert out[0] == out[1]
     assert all(len(s) > 0 for s in out[0][0])
+    # without injected noise: the packed pass leaves the device generator where the full-width pass leaves it
+    ends = []
+    for packed in (True, False):
+        if packed:
+            monkeypatch.undo()
+        else:
+            monkeypatch.setattr(gen_py, "_row_packing", lambda *a, **k: None)
+        torch.manual_seed(79)
+        seqs = gen_py.generate_full_mode_sequences(gen, tok, 5, pool, batch_size=4, device=DEV, rng_seed=5)
+        ends.append((seqs, torch.rand(4, device=DEV).tolist()))
+    assert ends[0] == ends[1]
 
 
 def test_save_and_load_pretrained_roundtrip(pg, tmp_path):
