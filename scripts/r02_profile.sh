@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile set: kernel trace of the default bench (2 timed steps), then two counter passes over
+# Profile set: kernel trace of the default bench (2 timed steps), then two counter passes over
 # scripts/pmc_gemm.py.  usage: scripts/r02_profile.sh <tag>   (writes gpurun_out/<tag>_*)
 set -o pipefail
 tag=$1
