@@ -10,13 +10,19 @@ constexpr int GBK = 64;
 constexpr int NT256 = 512;
 
 // ---- 256 x 256 tile over a ring of five 32-k half-stages (both operands k-major) -------------
-// The two-stage kernel above keeps one 64 KiB k-tile in flight and has to see it land within the
-// MFMAs of one k-tile (about 1.2 us), which the L2 / Infinity-Cache latency under load exceeds: a
-// k-tile takes 1.5 us.  Here the LDS (all 160 KiB) is a ring of five 32 KiB slots, each holding 32
-// k of the 256 A rows and the 256 B rows.  Slots are consumed one by one (32 MFMAs per wave), and
-// the loads of a whole 64-k tile (two slots, so that both halves of every 128-byte line are
-// requested together) are issued as soon as the second of its slots is free: three half-stages =
-// 1.5 k-tiles before the first of them is read, with up to two k-tiles (128 KiB) in flight.
+// The two-stage kernel of gemm.hip keeps one 64 KiB k-tile in flight and has to see it land within
+// the MFMAs of one k-tile (about 1.2 us); a k-tile takes it 1.5 - 1.65 us.  Here the LDS (all 160 KiB)
+// is a ring of five 32 KiB slots, each holding 32 k of the 256 A rows and the 256 B rows.  Slots are
+// consumed one by one (32 MFMAs per wave), and the loads of a whole 64-k tile (two slots) are issued
+// as soon as the second of its slots is free: three half-stages = 1.5 k-tiles before the first of
+// them is read, with up to two k-tiles (128 KiB) in flight.
+// Measured: the same speed as the two-stage kernel on every forward shape (a k-tile still takes
+// 1.65 us; 1.24 us with the loads compiled out, in both kernels), and 1 % slower inside the GAN step:
+// what the loop waits for is the rate at which the L2s deliver 64 KiB per k-tile to 256 CUs, not the
+// latency of one tile.  Off by default (pg_tune key 21); kept as the measured alternative.
+// The two 64-byte halves of every 128-byte operand line are requested back to back (pieces ordered
+// row group first, half second): with the halves half a stage apart the vector L1 had dropped the
+// line before its second half was asked for and the kernel ran 10 - 15 % slower.
 //   slot layout: A rows then B rows, 64 bytes per row; 16-byte chunk c of row r at position
 //   c ^ ((r >> 1) & 3), so that the eight lanes an LDS cycle serves (rows r..r+7, one chunk) fall
 //   into eight different 16-byte columns of the 256-byte bank line.
