@@ -916,6 +916,7 @@ int launch_glds_n64(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
 }
 
 int g_gemm_ring = 0;  // 1 = the five-slot ring kernel (gemm_ring.hip) for k-major x k-major products on 256x256 tiles (pg_tune key 21)
+int g_gemm_epi_prefetch = 1;  // bf16 epilogues fetch their per-element operand (pre-activation, residual or C) for the whole wave tile up front (pg_tune key 23)
 int g_gemm_nt_store_mb = 0;  // bf16 outputs of at least this many MiB leave with streaming stores (pg_tune key 22; 0 = never)
 int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 128x128 grid has <= 256 workgroups, 0 = never
 
@@ -970,6 +971,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 9) { if (value < 0 || value > 100) return PG_ERR_ARG; g_gemm_split_tail = value == 1 ? 50 : value; return PG_OK; }
   if (key == 19) { if (value < 0) return PG_ERR_ARG; g_gemm_small_grid = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
+  if (key == 23) { g_gemm_epi_prefetch = value ? 1 : 0; return PG_OK; }
   if (key == 22) { if (value < 0) return PG_ERR_ARG; g_gemm_nt_store_mb = value; return PG_OK; }
   if (key == 21) { g_gemm_ring = value ? 1 : 0; pg_internal_ring_dbg = value == 2; return PG_OK; }
   return PG_ERR_ARG;
@@ -1155,8 +1157,11 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
     if (d->residual) v8 = v8 && (d->ldr % 8 == 0) && (((uintptr_t)d->residual) % 16 == 0);
     if (d->aux) v8 = v8 && (d->ldaux % 8 == 0) && (((uintptr_t)d->aux) % 16 == 0);
     if (a.aux2) v8 = v8 && (((uintptr_t)a.aux2) % 16 == 0);
-    if (v8 && g_gemm_ep8) a.vec_ok = (g_gemm_nt_store_mb > 0 && (double)d->M * d->N * 2 >= g_gemm_nt_store_mb * 1048576.0 && d->beta == 0.f) ? 3 : 2;
+    if (v8 && g_gemm_ep8) {
+      a.vec_ok = (g_gemm_nt_store_mb > 0 && (double)d->M * d->N * 2 >= g_gemm_nt_store_mb * 1048576.0 && d->beta == 0.f) ? 3 : 2;
+    }
   }
+  if (a.vec_ok && g_gemm_epi_prefetch) a.vec_ok |= 4;  // (vec_ok: bits 0-1 = access width class, bit 2 = operand prefetch)
 
   return PG_OK;
 }

@@ -99,9 +99,20 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
   }
   const T* aux = reinterpret_cast<const T*>(g.aux);
   const T* res = reinterpret_cast<const T*>(g.residual);
+  // An accumulating product with no other per-element operand (the weight gradients: C += dY^T X) fetches C two row
+  // blocks at a time, eight loads in flight together; inside the loop below each load waits alone in its branch.
+  constexpr int PB = MI < 2 ? MI : 2;
+  const bool pre_c = (g.vec_ok & 4) && g.beta != 0.f && g.act != PG_ACT_MUL_DGELU && !res;
+  float cpre[PB][4][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const long m = m0 + i * 16;
+    if (i % PB == 0 && pre_c) {
+#pragma unroll
+      for (int i2 = 0; i2 < PB; ++i2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) VecIO<TC, 4>::load(Cp + (long)(m0 + (i + i2) * 16) * g.ldc + n0 + j * 16, cpre[i2][j]);
+    }
 #pragma unroll
     for (int jh = 0; jh < 4; jh += 2) {  // two column groups at a time keeps the live set small
       float v[2][4], u[2][4], r[2][4], c0[2][4];
@@ -114,8 +125,15 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
         for (int j = 0; j < 2; ++j) VecIO<T, 4>::load(res + m * g.ldr + n0 + (jh + j) * 16, r[j]);
       }
       if (g.beta != 0.f) {
+        if (pre_c) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) VecIO<TC, 4>::load(Cp + m * g.ldc + n0 + (jh + j) * 16, c0[j]);
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c0[j][e] = cpre[i % PB][jh + j][e];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) VecIO<TC, 4>::load(Cp + m * g.ldc + n0 + (jh + j) * 16, c0[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -171,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
                                                           int n_base, int lane) {
   const int gq = lane >> 4;
   const int m0 = m_base + (lane & 15);
-  const bool nt = g.vec_ok == 3;  // streaming stores of the output (pg_tune key 22)
+  const bool nt = (g.vec_ok & 3) == 3;  // streaming stores of the output (pg_tune key 22)
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
   const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
   // this lane's two column groups (jh = 0, 2) and their biases
@@ -188,6 +206,26 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
       for (int e = 0; e < 8; ++e) bv[h][e] = 0.f;
     }
   }
+  // The operand the epilogue reads per output element (the pre-activation of x GELU', else the residual, else C
+  // for an accumulate) is fetched four row blocks at a time, eight loads in flight together: read inside the
+  // loop below, each load sits in a branch of its own behind a full wait and the latencies follow one another.
+  // (All 2 MI loads of a 256x256 tile's wave at once cost that kernel twelve spilled registers.)
+  constexpr int PB = MI < 4 ? MI : 4;  // row blocks per batch
+  int pre_kind = 0;  // 1 = pre-activation (aux), 2 = residual, 3 = C
+  const bf16_t* pp = nullptr;
+  long pld = 0;
+  if (g.vec_ok & 4) {
+    if (g.act == PG_ACT_MUL_DGELU) { pp = aux; pld = g.ldaux; pre_kind = 1; }
+    else if (res) { pp = res; pld = g.ldr; pre_kind = 2; }
+    else if (g.beta != 0.f) { pp = Cp; pld = g.ldc; pre_kind = 3; }
+  }
+  uint4 pre[PB][2];
+  auto unpack8 = [](const uint4& q, float* o) {
+    o[0] = __uint_as_float(q.x << 16); o[1] = __uint_as_float(q.x & 0xffff0000u);
+    o[2] = __uint_as_float(q.y << 16); o[3] = __uint_as_float(q.y & 0xffff0000u);
+    o[4] = __uint_as_float(q.z << 16); o[5] = __uint_as_float(q.z & 0xffff0000u);
+    o[6] = __uint_as_float(q.w << 16); o[7] = __uint_as_float(q.w & 0xffff0000u);
+  };
   // Row block outermost: the two 64-byte halves of every 128-byte output line leave in consecutive
   // store instructions.  (Column group outermost put eight stores between them, and fabric-side
   // write bytes of a 4096-wide output measured 1.4x the output size: lines written back half full,
@@ -195,12 +233,24 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const long m = m0 + i * 16;
+    if (i % PB == 0 && pre_kind) {
+#pragma unroll
+      for (int i2 = 0; i2 < PB; ++i2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pre[i2][h] = *reinterpret_cast<const uint4*>(pp + (long)(m0 + (i + i2) * 16) * pld + nn[h]);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int jh = 2 * h;
       float v[8], u[8], r[8];
-      if (g.act == PG_ACT_MUL_DGELU) VecIO<bf16_t, 8>::load(aux + m * g.ldaux + nn[h], u);
-      if (res) VecIO<bf16_t, 8>::load(res + m * g.ldr + nn[h], r);
+      if (g.act == PG_ACT_MUL_DGELU) {
+        if (pre_kind == 1) unpack8(pre[i % PB][h], u);
+        else VecIO<bf16_t, 8>::load(aux + m * g.ldaux + nn[h], u);
+      }
+      if (res) {
+        if (pre_kind == 2) unpack8(pre[i % PB][h], r);
+        else VecIO<bf16_t, 8>::load(res + m * g.ldr + nn[h], r);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][jh][e]), __float_as_uint(acc[i][jh + 1][e]), false, false);
@@ -222,7 +272,8 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
       }
       if (g.beta != 0.f) {
         float c0[8];
-        VecIO<bf16_t, 8>::load(Cp + m * g.ldc + nn[h], c0);
+        if (pre_kind == 3) unpack8(pre[i % PB][h], c0);
+        else VecIO<bf16_t, 8>::load(Cp + m * g.ldc + nn[h], c0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
       }
@@ -239,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArg
                                               int n_base, int lane) {
   if (interior) {
     if constexpr (sizeof(T) == 2 && sizeof(TC) == 2) {
-      if (g.vec_ok >= 2) {
+      if ((g.vec_ok & 3) >= 2) {
         gemm_epilogue_interior_b8<MI>(acc, g, Cp, m_base, n_base, lane);
         return;
       }
