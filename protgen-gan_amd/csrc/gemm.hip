@@ -271,10 +271,7 @@ int launch_layout(const pg_gemm_desc* d, const GemmArgs& a, dim3 grid, hipStream
 //   m-major tile [64 k][128 bf16]   (256-B rows):  chunk c of row k sits at position c ^ swz(k),
 //                                                  swz(k) = ((k & 3) << 2) | ((k >> 2) & 3)
 // Requires K % 64 == 0 (whole tiles only: nothing can be masked on the way into LDS).
-constexpr int GBK = 64;
-constexpr int GT_ELEMS = 128 * GBK;  // 8192 bf16 = 16 KiB per operand tile
-
-__device__ __forceinline__ int swz_m(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
+#include "gemm_tile256.h"  // GBK, GT_ELEMS, swizzles, fragment offsets / reads, the 256-tile k-tile body
 
 template <bool KMAJOR>
 __device__ __forceinline__ void glds_stage(const bf16_t* __restrict__ base, long ld, int row0, int rows_max, int k0,
@@ -300,56 +297,6 @@ __device__ __forceinline__ void glds_stage(const bf16_t* __restrict__ base, long
   }
 }
 
-// Fragment reads are inline asm: a compiler-visible ds_read of the staging array makes hipcc
-// wait vmcnt(0) first (it cannot tell which in-flight LDS-DMA it may alias), which would
-// drain the prefetch ring before every k-tile.  The waits are therefore counted by hand:
-// reads return in issue order, lgkmcnt(n) = "all but the n youngest have returned".
-// Per-lane byte offsets (inside one 16 KiB operand tile) of the fragments a lane reads; they do
-// not depend on the k-tile, so they are computed once per kernel.
-//   k-major: off[kk]; tile row block i adds i*2048 (immediate)
-//   m-major: off[hi*4 + i]; k-step kk adds kk*8192 (immediate)
-template <bool KMAJOR> struct FragOff { unsigned off[KMAJOR ? 2 : 8]; };
-
-template <bool KMAJOR>
-__device__ __forceinline__ FragOff<KMAJOR> frag_offsets(int wsel, int lane) {
-  FragOff<KMAJOR> f;
-  const int r = lane & 15, g = lane >> 4;
-  if constexpr (KMAJOR) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) f.off[kk] = (unsigned)((wsel * 64 + r) * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
-  } else {
-    const int q = r >> 2, pp = r & 3;
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = 8 * g + q + 4 * hi;
-        const int ch = wsel * 8 + 2 * i + (pp >> 1);
-        f.off[hi * 4 + i] = (unsigned)(k * 256 + ((ch ^ swz_m(k)) << 4) + 8 * (pp & 1));
-      }
-  }
-  return f;
-}
-
-template <bool KMAJOR, int KK>
-__device__ __forceinline__ void read_frags(unsigned tile_addr, const FragOff<KMAJOR>& f, u32x4 (&out)[4]) {
-  if constexpr (KMAJOR) {
-    const unsigned a = tile_addr + f.off[KK];
-    out[0] = lds_read_b128<0>(a);
-    out[1] = lds_read_b128<2048>(a);
-    out[2] = lds_read_b128<4096>(a);
-    out[3] = lds_read_b128<6144>(a);
-  } else {
-#define PG_TR_PAIR(I)                                                         \
-    {                                                                         \
-      u32x2 lo = lds_read_tr_b64<KK * 8192>(tile_addr + f.off[I]);           \
-      u32x2 hi = lds_read_tr_b64<KK * 8192>(tile_addr + f.off[4 + I]);       \
-      out[I] = (u32x4){lo[0], lo[1], hi[0], hi[1]};                          \
-    }
-    PG_TR_PAIR(0) PG_TR_PAIR(1) PG_TR_PAIR(2) PG_TR_PAIR(3)
-#undef PG_TR_PAIR
-  }
-}
 
 template <bool AK, bool BK_>
 __device__ __forceinline__ void glds_compute(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa, const FragOff<BK_>& fb,
@@ -508,7 +455,6 @@ int launch_glds_pair(const pg_gemm_desc* d, const GemmArgs2& a, int blocks, hipS
 // fragment addressing are shared with the 128x128 kernel).  A wave keeps 128 accumulator
 // registers and walks a k-tile in four chunks (k-step x row half), each chunk's fragment reads
 // issued one chunk ahead of the MFMAs that consume them.
-constexpr int NT256 = 512;
 int g_gemm_dbg = 0;
 
 
@@ -521,96 +467,6 @@ __device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const u32x4
                                                                acc[i0 + i][j], 0, 0, 0);
 }
 
-// Per-lane byte offsets (from the workgroup's first operand row / column) of the four 1 KiB
-// pieces a wave copies of one 128-row sub-tile; the k-tile only moves the uniform base.
-template <bool KMAJOR>
-__device__ __forceinline__ void piece_offsets(long ld, int blk0, int half, int extent, int w4, int lane, unsigned (&off)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = w4 * 4 + j;
-    if constexpr (KMAJOR) {
-      const int c = (lane & 7) ^ (lane >> 3);
-      int rg = blk0 + half * 128 + 8 * i + (lane >> 3);
-      rg = rg < extent ? rg : extent - 1;
-      off[j] = (unsigned)(((long)(rg - blk0) * ld + c * 8) * 2);
-    } else {
-      const int k = 4 * i + (lane >> 4);
-      const int c = (lane & 15) ^ swz_m(k);
-      int m = blk0 + half * 128 + c * 8;
-      m = m <= extent - 8 ? m : extent - 8;
-      off[j] = (unsigned)(((long)k * ld + (m - blk0)) * 2);
-    }
-  }
-}
-
-
-// One k-tile of one wave: 64 MFMAs in four chunks (k-step x row half), each chunk's fragment
-// reads issued one chunk ahead.  With LOAD the wave's eight LDS-DMA pieces of the next k-tile
-// are issued one per four MFMAs inside the first two chunks: a piece holds the issuing wave for
-// tens of cycles, so a burst of eight at the top of the tile would idle the matrix pipe.  The
-// two waves that share a SIMD use opposite phases (PH: piece before / after its four MFMAs) so
-// one of them is always feeding the pipe.
-template <bool AK, bool BK_, int PH, bool LOAD, bool MATH>
-__device__ __forceinline__ void glds256_tile(unsigned a_addr, unsigned b_addr, const FragOff<AK>& fa_lo, const FragOff<AK>& fa_hi,
-                                             const FragOff<BK_>& fb, f32x4 (&acc)[8][4], const char* a_src, const char* b_src,
-                                             const unsigned (&aoff)[4], const unsigned (&boff)[4], bf16_t* a_dst, bf16_t* b_dst) {
-  constexpr int NA = AK ? 4 : 8, NB = BK_ ? 4 : 8;  // LDS reads per group of four fragments
-  if constexpr (!MATH) {
-    if constexpr (LOAD) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(a_src + aoff[j], a_dst + j * 512, 16, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(b_src + boff[j], b_dst + j * 512, 16, 0, 0);
-    }
-    return;
-  }
-  u32x4 b0[4], b1[4], a00[4], a01[4], a10[4], a11[4];
-  read_frags<BK_, 0>(b_addr, fb, b0);
-  read_frags<AK, 0>(a_addr, fa_lo, a00);
-  read_frags<AK, 0>(a_addr, fa_hi, a01);
-  lgkm_wait<NA>();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if constexpr (LOAD && PH == 0) {
-      __builtin_amdgcn_global_load_lds(a_src + aoff[g], a_dst + g * 512, 16, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mfma_row(acc[g], a00[g], b0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LOAD && PH == 1) {
-      __builtin_amdgcn_global_load_lds(a_src + aoff[g], a_dst + g * 512, 16, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  read_frags<BK_, 1>(b_addr, fb, b1);
-  read_frags<AK, 1>(a_addr, fa_lo, a10);
-  lgkm_wait<NA + NB>();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if constexpr (LOAD && PH == 0) {
-      __builtin_amdgcn_global_load_lds(b_src + boff[g], b_dst + g * 512, 16, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mfma_row(acc[4 + g], a01[g], b0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LOAD && PH == 1) {
-      __builtin_amdgcn_global_load_lds(b_src + boff[g], b_dst + g * 512, 16, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  read_frags<AK, 1>(a_addr, fa_hi, a11);
-  lgkm_wait<NA>();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) mfma_row(acc[g], a10[g], b1);
-  __builtin_amdgcn_sched_barrier(0);
-  lgkm_wait<0>();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) mfma_row(acc[4 + g], a11[g], b1);
-}
 
 template <bool AK, bool BK_, int PH, int DBG>
 __device__ __forceinline__ void glds256_mainloop(const GemmArgs& g, const bf16_t* A, const bf16_t* B, const bf16_t* A2,
@@ -916,6 +772,7 @@ int launch_glds_n64(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
 }
 
 int g_gemm_ring = 0;  // 1 = the five-slot ring kernel (gemm_ring.hip) for k-major x k-major products on 256x256 tiles (pg_tune key 21)
+int g_gemm_persist = 0;  // 256-tile products (A k-major) with more tiles than workgroups run persistent workgroups that walk their tiles (gemm_persist.hip; pg_tune key 24): 1 = one per CU, n > 1 = n workgroups, 0 = off
 int g_gemm_epi_prefetch = 1;  // bf16 epilogues fetch their per-element operand (pre-activation, residual or C) for the whole wave tile up front (pg_tune key 23)
 int g_gemm_nt_store_mb = 0;  // bf16 outputs of at least this many MiB leave with streaming stores (pg_tune key 22; 0 = never)
 int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 128x128 grid has <= 256 workgroups, 0 = never
@@ -940,6 +797,7 @@ int g_gemm_deep_max_blocks = 256;
 }  // namespace
 
 int pg_internal_launch_ring256(const void* args, int M, int N, int c_is_f32, hipStream_t st);
+int pg_internal_launch_persist256(const void* args, int M, int N, int b_kmajor, int c_is_f32, int workgroups, hipStream_t st);
 extern int pg_internal_ring_dbg;
 int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
 
@@ -971,6 +829,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 9) { if (value < 0 || value > 100) return PG_ERR_ARG; g_gemm_split_tail = value == 1 ? 50 : value; return PG_OK; }
   if (key == 19) { if (value < 0) return PG_ERR_ARG; g_gemm_small_grid = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
+  if (key == 24) { if (value < 0) return PG_ERR_ARG; g_gemm_persist = value; return PG_OK; }
   if (key == 23) { g_gemm_epi_prefetch = value ? 1 : 0; return PG_OK; }
   if (key == 22) { if (value < 0) return PG_ERR_ARG; g_gemm_nt_store_mb = value; return PG_OK; }
   if (key == 21) { g_gemm_ring = value ? 1 : 0; pg_internal_ring_dbg = value == 2; return PG_OK; }
@@ -1064,6 +923,9 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
     else rc = launch_glds_n64<bf16_t>(d, a, st);
   } else if (wide && g_gemm_ring && d->a_kmajor && d->b_kmajor && d->batch == 1 && d->K + d->K2 >= 2 * GBK) {
     rc = pg_internal_launch_ring256(&a, d->M, d->N, d->c_dtype == PG_F32, st);
+  } else if (wide && g_gemm_persist && d->a_kmajor && d->batch == 1 && g_gemm_dbg == 0 &&
+             tiles256(d) > (g_gemm_persist == 1 ? device_cus() : g_gemm_persist)) {
+    rc = pg_internal_launch_persist256(&a, d->M, d->N, d->b_kmajor, d->c_dtype == PG_F32, g_gemm_persist == 1 ? device_cus() : g_gemm_persist, st);
   } else if (wide) {
     if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
     else rc = launch_glds256<bf16_t>(d, a, st);

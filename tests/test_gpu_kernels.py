@@ -26,6 +26,7 @@ def pg():
 
 DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
+PERSIST_DEFAULT = 0  # the library's initial pg_tune key 24
 
 
 def tol(dtype):
@@ -79,12 +80,16 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull, narrow):
     assert torch.equal(out.cpu().double(), ref)
 
 
-@pytest.fixture(params=[1, 0], ids=["ring", "two_stage"])
+@pytest.fixture(params=[(1, 0), (0, 0), (0, 8), (0, 3)], ids=["ring", "two_stage", "persistent8", "persistent3"])
 def ring(request, pg):
-    """Both 256x256-tile kernels for k-major x k-major products: the two-stage one (default) and the five-slot ring."""
-    pg._lib.lib.pg_tune(21, request.param)
+    """Every 256x256-tile kernel: the two-stage one, the five-slot ring (k-major x k-major products) and the
+    persistent form (A k-major), here with 8 and with 3 workgroups so that the few tiles of a test shape are
+    more than one per workgroup (unevenly: some walk two or three tiles, some one)."""
+    pg._lib.lib.pg_tune(21, request.param[0])
+    pg._lib.lib.pg_tune(24, request.param[1])
     yield request.param
     pg._lib.lib.pg_tune(21, 0)
+    pg._lib.lib.pg_tune(24, PERSIST_DEFAULT)
 
 
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
