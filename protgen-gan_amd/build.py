@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if jobs or not os.path.exists(LIB_PATH):
+    if jobs or not os.path.exists(LIB_PATH) or any(_newer(o, LIB_PATH) for o in objs):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH],
                            capture_output=True, text=True)
         if r.returncode != 0:
