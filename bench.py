@@ -51,8 +51,8 @@ def f_c(B, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["train", "generate"], default="train")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--gen-batch", type=int, default=4)
