@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue<T, TC, 4>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
+  gemm_epilogue<T, TC, 4>(acc, g, Cp, g.vec_ok && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
 }
 
 template <typename T, typename TC>
@@ -387,7 +387,7 @@ __device__ __forceinline__ void glds_body(bf16_t* smem, const GemmArgs& g, const
       glds_compute<AK, BK_>(la, la + 2 * GT_ELEMS, fa, fb, acc);
     }
   }
-  gemm_epilogue<bf16_t, TC, 4>(acc, g, Cp, g.vec_ok && bm + BM <= g.M && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
+  gemm_epilogue<bf16_t, TC, 4>(acc, g, Cp, g.vec_ok && bn + BN <= g.N, bm + wr * 64, bn + wc * 64, lane);
 }
 
 
@@ -541,7 +541,7 @@ __device__ __forceinline__ void glds256_block(const GemmArgs& g, const bf16_t* A
   // waves w and w + 4 share a SIMD: opposite piece phases
   if (wr == 0) glds256_mainloop<AK, BK_, 0, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
   else glds256_mainloop<AK, BK_, 1, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
-  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
+  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
 }
 
 template <typename TC, bool AK, bool BK_, int DBG = 0>
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_n64_kernel(GemmArgs g) 
                                                               __builtin_bit_cast(bf16x8_t, af[kk][i]), acc[i][j], 0, 0, 0);
     __syncthreads();
   }
-  gemm_epilogue<bf16_t, TC, 2>(acc, gl, Cp, g.vec_ok && bm + BM <= gl.M && bn + 64 <= g.N, bm + wid * 32, bn, lane);
+  gemm_epilogue<bf16_t, TC, 2>(acc, gl, Cp, g.vec_ok && bn + 64 <= g.N, bm + wid * 32, bn, lane);
 }
 
 template <typename TC>
@@ -787,7 +787,7 @@ int g_gemm_small_grid = 0;  // most 128x128 tiles of an unbatched product that t
 int g_gemm_split_tail = 50;  // 256-tile products: the rows of a last round less than this many per cent full go to a second launch (0 = never)
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
-int g_gemm_wide_min_tiles = 160;  // fewest 256x256 tiles at which a narrow-N (512 <= N < 2048) product takes the 256x256 kernel
+int g_gemm_wide_min_tiles = 129;  // fewest 256x256 tiles at which a narrow-N (512 <= N < 2048) product takes the 256x256 kernel (pg_tune key 14)
 int g_gemm_path = 1;  // 0 = register-staged kernel, 1 = direct-to-LDS (ring depth by grid size), 2/4 = force that depth
 // largest 128x128 grid that takes the four-buffer ring (one workgroup per CU): measured on 16 cold operand sets, the
 // ring wins at 152 workgroups (N = 1024 products of 2432 rows: 44 vs 65 us at K = 4096) and loses from 360 on
@@ -878,8 +878,10 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
                               (d->K2 == 0 && g_gemm_narrow == 1 && d->batch == 1 && !d->seq_off && blocks128 <= g_gemm_small_grid));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
-                     // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round down to
-                     // 160 tiles (192 tiles on 256 CUs beat 768 tiles of 128x128 by 17 %; at 128 tiles they lose)
+                     // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round as soon as the
+                     // 128x128 tiles no longer fit the chip at once (192 tiles on 256 CUs beat 768 tiles of 128x128
+                     // by 17 %; 130 tiles beat 520 by 5 % at K 1024 and 10 % at K 4096; at 128 tiles = 512 of
+                     // 128x128, all resident together, they lose 28 against 37 us)
                      (g_gemm_wide == 1 && d->N >= 512 && d->K >= g_gemm_wide_min_k && tiles256(d) >= g_gemm_wide_min_tiles));
   if (d->K2 > 0 && (!fast || !g_gemm_dualk || (d->batch != 1 && !narrow))) {
     // only the 128x128 and 256x256 direct-to-LDS kernels walk two reduction segments: elsewhere two launches

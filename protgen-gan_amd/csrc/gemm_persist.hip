@@ -114,7 +114,7 @@ __device__ __forceinline__ void persist_run(const GemmArgs& g, bf16_t* smem, int
     // the k-loop, which has no registers to spare)
     int elane = lane;
     asm volatile("" : "+v"(elane));
-    gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && cm + 256 <= g.M && cn + 256 <= g.N, cm + wr * 128, cn + wc * 64, elane);
+    gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && cn + 256 <= g.N, cm + wr * 128, cn + wc * 64, elane);
     if (!more) break;  // (uniform: every wave of the workgroup leaves here)
     id = next;
   }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT256, 1) void gemm_ring256_kernel(GemmArgs g) {
   const bf16_t* B2 = reinterpret_cast<const bf16_t*>(g.B2);
   if (wr == 0) ring256_mainloop<0, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
   else ring256_mainloop<1, DBG>(g, A, B, A2, B2, bm, bn, smem, wid, lane, acc);
-  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bm + 256 <= g.M && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
+  gemm_epilogue<bf16_t, TC, 8>(acc, g, Cp, g.vec_ok && bn + 256 <= g.N, bm + wr * 128, bn + wc * 64, lane);
 }
 
 }  // namespace

@@ -87,6 +87,9 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
                                                        int lane) {
   const int n0 = n_base + 4 * (lane >> 4);
   const int m0 = m_base + (lane & 15);
+  // A tile over the lower edge of C: rows past the last one are computed and never stored; what the epilogue
+  // reads for them comes from the last row, so every load stays unconditional.
+  const int m_last = g.M - 1;
   float bv[4][4];
   if (g.bias) {
 #pragma unroll
@@ -106,12 +109,15 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
   float cpre[PB][4][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const long m = m0 + i * 16;
+    const bool row_ok = m0 + i * 16 <= m_last;
+    const long m = row_ok ? m0 + i * 16 : m_last;
     if (i % PB == 0 && pre_c) {
 #pragma unroll
-      for (int i2 = 0; i2 < PB; ++i2)
+      for (int i2 = 0; i2 < PB; ++i2) {
+        const int mp = m0 + (i + i2) * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) VecIO<TC, 4>::load(Cp + (long)(m0 + (i + i2) * 16) * g.ldc + n0 + j * 16, cpre[i2][j]);
+        for (int j = 0; j < 4; ++j) VecIO<TC, 4>::load(Cp + (long)(mp <= m_last ? mp : m_last) * g.ldc + n0 + j * 16, cpre[i2][j]);
+      }
     }
 #pragma unroll
     for (int jh = 0; jh < 4; jh += 2) {  // two column groups at a time keeps the live set small
@@ -140,7 +146,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[j][e] = acc[i][jh + j][e] * g.alpha + bv[jh + j][e];
       if (g.act == PG_ACT_GELU) {
-        if (g.aux) {
+        if (g.aux && row_ok) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             VecIO<T, 4>::store(reinterpret_cast<T*>(g.aux) + m * g.ldaux + n0 + (jh + j) * 16, v[j]);
@@ -150,7 +156,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[j][e] = gelu_epi<T>(v[j][e]);
       } else if (g.act == PG_ACT_MUL_DGELU) {
-        if (g.aux2) {
+        if (g.aux2 && row_ok) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             VecIO<T, 4>::store(reinterpret_cast<T*>(g.aux2) + m * g.ldaux + n0 + (jh + j) * 16, v[j]);
@@ -172,8 +178,10 @@ __device__ __forceinline__ void gemm_epilogue_interior(f32x4 (&acc)[MI][4], cons
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[j][e] += g.beta * c0[j][e];
       }
+      if (row_ok) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) VecIO<TC, 4>::store(Cp + m * g.ldc + n0 + (jh + j) * 16, v[j]);
+        for (int j = 0; j < 2; ++j) VecIO<TC, 4>::store(Cp + m * g.ldc + n0 + (jh + j) * 16, v[j]);
+      }
     }
   }
 }
@@ -189,6 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
                                                           int n_base, int lane) {
   const int gq = lane >> 4;
   const int m0 = m_base + (lane & 15);
+  const int m_last = g.M - 1;  // (rows past it: computed, never stored, their operands read from row m_last)
   const bool nt = (g.vec_ok & 3) == 3;  // streaming stores of the output (pg_tune key 22)
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
   const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
@@ -232,12 +241,15 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
   // then again.)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const long m = m0 + i * 16;
+    const bool row_ok = m0 + i * 16 <= m_last;
+    const long m = row_ok ? m0 + i * 16 : m_last;
     if (i % PB == 0 && pre_kind) {
 #pragma unroll
-      for (int i2 = 0; i2 < PB; ++i2)
+      for (int i2 = 0; i2 < PB; ++i2) {
+        const int mp = m0 + (i + i2) * 16;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) pre[i2][h] = *reinterpret_cast<const uint4*>(pp + (long)(m0 + (i + i2) * 16) * pld + nn[h]);
+        for (int h = 0; h < 2; ++h) pre[i2][h] = *reinterpret_cast<const uint4*>(pp + (long)(mp <= m_last ? mp : m_last) * pld + nn[h]);
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -258,11 +270,11 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
         v[4 + e] = __uint_as_float(sw[1]) * g.alpha + bv[h][4 + e];
       }
       if (g.act == PG_ACT_GELU) {
-        if (g.aux) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux) + m * g.ldaux + nn[h], v);
+        if (g.aux && row_ok) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux) + m * g.ldaux + nn[h], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
       } else if (g.act == PG_ACT_MUL_DGELU) {
-        if (g.aux2) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux2) + m * g.ldaux + nn[h], v);
+        if (g.aux2 && row_ok) VecIO<bf16_t, 8>::store(reinterpret_cast<bf16_t*>(g.aux2) + m * g.ldaux + nn[h], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_d1_fast(u[e]);
       }
@@ -277,13 +289,16 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
       }
-      if (nt) VecIO<bf16_t, 8>::store_nt(Cp + m * g.ldc + nn[h], v);
-      else VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
+      if (row_ok) {
+        if (nt) VecIO<bf16_t, 8>::store_nt(Cp + m * g.ldc + nn[h], v);
+        else VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
+      }
     }
   }
 }
 
-// `interior`: the whole workgroup tile lies inside C and every operand is vector-aligned.
+// `interior`: the workgroup tile's columns all lie inside C and every operand is vector-aligned (the tile may
+// hang over the lower edge: the vector paths skip the rows past M).
 // (m_base, n_base): first row / column of this wave's MI x 4 grid of 16x16 tiles.
 template <typename T, typename TC, int MI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4], const GemmArgs& g, TC* Cp, bool interior, int m_base,
