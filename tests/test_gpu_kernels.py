@@ -261,6 +261,45 @@ def test_gemm_wide_tile_split_last_round(pg, ring):
     close(out, K_gelu(ref / 64 + bias.double()), bf)
 
 
+@pytest.mark.parametrize("kernel", ["128", "256", "n64"])
+@pytest.mark.parametrize("M", [8, 72, 136, 250])
+def test_gemm_lower_edge_rows(pg, kernel, M):
+    """A tile that hangs over the lower edge of C leaves through the vector epilogue with the rows past M unstored:
+    for every epilogue option, rows [0, M) carry the same bits as the same rows of a product whose M fills whole
+    tiles, and the rows of the output buffers behind M keep what they held (outputs are views of taller buffers)."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(900 + M)
+    Mfull, N, Kd = 512, (64 if kernel == "n64" else 512), 192
+    A = rnd(Mfull, Kd, dtype=bf, gen=g).to(bf).to(DEV)
+    B = rnd(N, Kd, dtype=bf, scale=0.05, gen=g).to(bf).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = rnd(Mfull, N, dtype=bf, gen=g).to(bf).to(DEV)
+    U = rnd(Mfull, N, dtype=bf, gen=g).to(bf).to(DEV)
+    C0 = torch.randn(Mfull, N, generator=g)
+    SENT = 12345.0
+
+    def run(m):
+        outs = {}
+        tall = lambda dt=bf: torch.full((Mfull, N), SENT, dtype=dt, device=DEV)  # noqa: E731
+        c = tall(); pg.ops.gemm(A[:m], B, c[:m], bias=bias, residual=res[:m]); outs["bias_res"] = c
+        c, a = tall(), tall(); pg.ops.gemm(A[:m], B, c[:m], bias=bias, act=pg._lib.PG_ACT_GELU, aux=a[:m])
+        outs["gelu"], outs["gelu_aux"] = c, a
+        c, a = tall(), tall(); pg.ops.gemm(A[:m], B, c[:m], act=pg._lib.PG_ACT_MUL_DGELU, aux=U[:m], aux2=a[:m])
+        outs["dgelu"], outs["dgelu_aux2"] = c, a
+        c = tall(torch.float32); c[:m] = C0[:m].to(DEV); pg.ops.gemm(A[:m], B, c[:m], alpha=0.5, beta=1.0); outs["acc_f32"] = c
+        c = tall(); c[:m] = C0[:m].to(bf).to(DEV); pg.ops.gemm(A[:m], B, c[:m], beta=1.0); outs["acc_bf16"] = c
+        return outs
+
+    pg._lib.lib.pg_tune(2, 2 if kernel == "256" else (0 if kernel == "128" else 1))
+    try:
+        edge, full = run(M), run(Mfull)
+    finally:
+        pg._lib.lib.pg_tune(2, 1)
+    for name in edge:
+        assert torch.equal(edge[name][:M], full[name][:M]), name
+        assert bool((edge[name][M:] == SENT).all()), name
+
+
 def test_gemm_split_last_round_two_segments(pg, ring):
     """The same split with a second reduction segment and a k-major A: the rows that go to the second
     launch must take the same rows of A2.  Exact integers against two plain products."""
