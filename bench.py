@@ -48,6 +48,22 @@ def f_c(B, S):
     return B * S * f_enc(S) + B * 1343616
 
 
+def f_row(n):
+    """One sequence of n token rows through the encoder + critic head, forward."""
+    return n * f_enc(n) + 1343616
+
+
+def gemm_source_digest():
+    """Digest of the GEMM kernel sources: a counter capture under profiles/ carries the digest of the sources it was
+    taken on, and only a capture of the current sources is quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "protgen-gan_amd", "csrc", "gemm*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +99,13 @@ def main():
     from protgen_gan_amd._lib import lib
 
     rank, local, world = pgd.init_from_env()
+    if torch.distributed.is_initialized():
+        # the ranks the process group actually has, not what the environment announced
+        world = torch.distributed.get_world_size()
+        rank = torch.distributed.get_rank()
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -160,13 +183,21 @@ def main():
     fence()
     generator.fill_shapes.clear()
     generator.fill_widths.clear()
+    del pgt.EXEC_LOG[:]
     lib.pg_profile_begin(args.profile_sample)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fills_seen, fill_rows = 0, []
     t0 = time.perf_counter()
+    marks[0].record()
     last = None
     for i in range(args.warmup, total):
         last = one_step(i)
+        marks[i - args.warmup + 1].record()
+        fill_rows.append(sum(B * S for B, S in generator.fill_shapes[fills_seen:]))
+        fills_seen = len(generator.fill_shapes)
     fence()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     prof = (ctypes.c_double * 48)()
     nl = ctypes.c_int64(0)
     lib.pg_profile_end(prof, ctypes.byref(nl))
@@ -186,18 +217,20 @@ def main():
     critic_flops = args.steps * args.n_critic * fe_critic * f_c(args.batch, args.seq)
     gen_flops = args.steps * fe_gen * f_c(args.gen_batch if seeds is None else args.batch, args.seq)
     flops_step = (fill_flops + critic_flops + gen_flops) / args.steps
+    # the same accounting on the token rows the updates actually launched: a ragged update runs every sequence on its
+    # own leading columns (no pad rows), so the padded-width figure above counts work that is never executed.  Per
+    # sequence of n rows: gradient-penalty interpolate 6 (frozen 3) forward-equivalents, scored row 3 (frozen 1).
+    fe_gp, fe_sc = (6, 3) if args.regime == "unfrozen" else (3, 1)
+    exec_critic = sum(fe_gp * sum(f_row(n) for n in gl) + fe_sc * sum(f_row(n) for n in sl)
+                      for kind, gl, sl in pgt.EXEC_LOG if kind == "critic")
+    exec_gen = sum(fe_sc * sum(f_row(n) for n in sl) for kind, gl, sl in pgt.EXEC_LOG if kind == "generator")
+    if soft:
+        exec_gen = gen_flops  # (the soft update runs rectangular)
+    exec_rows = sum(sum(gl) + sum(sl) for _, gl, sl in pgt.EXEC_LOG)
+    flops_step_exec = (fill_flops + exec_critic + exec_gen) / args.steps
     ms_step = dt / args.steps * 1e3
 
-    variants = []
-    for v in range(16):
-        n, fl, ms = prof[v * 3], prof[v * 3 + 1], prof[v * 3 + 2]
-        if n > 0:
-            variants.append({"kernel": VARIANT_NAMES.get(v, f"gemm_variant_{v}"), "sampled_launches": int(n),
-                             "avg_us": ms / n * 1e3, "tflops": fl / (ms * 1e-3) / 1e12, "time_share_of_gemm": ms})
-    tot_ms = sum(v["time_share_of_gemm"] for v in variants) or 1.0
-    for v in variants:
-        v["time_share_of_gemm"] = round(v["time_share_of_gemm"] / tot_ms, 4)
-    variants.sort(key=lambda v: -v["time_share_of_gemm"])
+    variants = variant_table(prof)
     dom = variants[0] if variants else None
     # fabric-side bytes per launch of the dominant kernel's largest shape, from the newest counter capture committed
     # under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/pmc_gemm.py, summarised by
@@ -207,11 +240,17 @@ def main():
     if caps:
         try:
             with open(caps[-1]) as fh:
-                shapes = {e["shape"]: e for e in json.load(fh)["shapes"]}
+                cap = json.load(fh)
+            shapes = {e["shape"]: e for e in cap["shapes"]}
             e = shapes.get("fill_w1")
-            if e:
+            if e and cap.get("gemm_source_digest") != gemm_source_digest():
+                # the GEMM kernels changed after the capture: its bytes describe another binary
+                traffic_note = (f"{os.path.basename(caps[-1])} was captured on GEMM sources {cap.get('gemm_source_digest')}, "
+                                f"this run's are {gemm_source_digest()}: not quoted")
+            elif e:
                 traffic = int(e["fetch_bytes_median"] + e["write_bytes_median"])
-                traffic_note = (f"{os.path.basename(caps[-1])}: fill-pass W1 product M {e['M']} N {e['N']} K {e['K']} (the dominant "
+                traffic_note = (f"{os.path.basename(caps[-1])} (GEMM sources {cap['gemm_source_digest']}): fill-pass W1 product "
+                                f"M {e['M']} N {e['N']} K {e['K']} (the dominant "
                                 f"kernel's largest launch): fetched {e['fetch_bytes_median'] / 1e6:.0f} MB = {e['fetch_over_operands']} x its "
                                 f"operands, wrote {e['write_bytes_median'] / 1e6:.0f} MB = {e['write_over_output']} x its output")
         except (OSError, KeyError, ValueError):
@@ -238,24 +277,52 @@ def main():
                    "generator_update": "soft embeddings through the critic's 3-D branch" if soft else "token ids (reference loop)",
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
                    "weights": "ProtBERT architecture, seeded random init", "lengths": f"uniform {pool[0]}..{pool[-1]} (DNMT-length stand-in)"},
+        # two prices of the same step.  "algorithmic": every update at the padded width the reference runs (len 512);
+        # "executed": every update at the token rows actually launched (ragged rows, no pads).  The first says how
+        # fast the reference's step is being done, the second how busy the matrix pipes are.
         "algorithmic_tflop_per_step": round(flops_step / 1e12, 2),
         "step_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 2),
         "step_mfma_frac": round(flops_step / (dt / args.steps) / MFMA_PEAK_BF16, 4),
+        "executed_tflop_per_step": round(flops_step_exec / 1e12, 2),
+        "step_mfma_frac_executed": round(flops_step_exec / (dt / args.steps) / MFMA_PEAK_BF16, 4),
+        "executed_update_rows_per_step": round(exec_rows / args.steps, 1),
+        "step_ms": {"min": round(min(step_ms), 2), "median": round(sorted(step_ms)[len(step_ms) // 2], 2),
+                    "max": round(max(step_ms), 2), "each": [round(v, 1) for v in step_ms],
+                    "fill_token_rows_each": fill_rows},
         "c_loss": c_loss, "g_loss": g_loss,
         "roofline": roofline, "gemm_variants": variants,
     }
     # the other half of the metric, after and outside the train leg's timed region: generated sequences/s
     if not args.no_generate_leg:
-        out["generate"] = time_generate(pg, generator, pool, rank, world, dev, batches=args.generate_batches)
+        out["generate"] = time_generate(pg, generator, pool, rank, world, dev, batches=args.generate_batches,
+                                        profile_sample=args.profile_sample)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, pg, dev)
+            if "generate" in out:
+                out["generate"]["cpu_baseline"] = out["cpu_baseline"].pop("generate")
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
-def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1, bs=64):
+def variant_table(prof):
+    """pg_profile_end's table (per GEMM operand layout: sampled launches, their FLOPs, their milliseconds from HIP
+    events on the launch stream) as a list, largest time share first."""
+    variants = []
+    for v in range(16):
+        n, fl, ms = prof[v * 3], prof[v * 3 + 1], prof[v * 3 + 2]
+        if n > 0:
+            variants.append({"kernel": VARIANT_NAMES.get(v, f"gemm_variant_{v}"), "sampled_launches": int(n),
+                             "avg_us": ms / n * 1e3, "tflops": fl / (ms * 1e-3) / 1e12, "time_share_of_gemm": ms})
+    tot_ms = sum(v["time_share_of_gemm"] for v in variants) or 1.0
+    for v in variants:
+        v["time_share_of_gemm"] = round(v["time_share_of_gemm"] / tot_ms, 4)
+    variants.sort(key=lambda v: -v["time_share_of_gemm"])
+    return variants
+
+
+def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1, bs=64, profile_sample=16):
     """generate.py's full mode (batch 64 per GPU, lengths from the pool, 10 fill iterations): sequences/s over
     `batches` batches per rank, summed over ranks (every rank fills its own sequences: no collective)."""
     from protgen_gan_amd import generate as gen_py
@@ -268,45 +335,69 @@ def time_generate(pg, generator, pool, rank, world, dev, batches, warm_batches=1
         torch.distributed.barrier()
     generator.fill_shapes.clear()
     generator.fill_widths.clear()
+    from protgen_gan_amd._lib import lib
+    lib.pg_profile_begin(profile_sample)
     t0 = time.perf_counter()
     seqs = gen_py.generate_full_mode_sequences(generator, tok, n, pool, batch_size=bs, device=str(dev), rng_seed=42 + rank)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 48)()
+    nl = ctypes.c_int64(0)
+    lib.pg_profile_end(prof, ctypes.byref(nl))
+    variants = variant_table(prof)
     if world > 1:
         t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    # algorithmic FLOPs: every row at its own length L + 2 (batch padding to the longest row is not work the path asks for)
-    flops = sum(B * S * f_gen_tok(S) if w is None else sum(x * f_gen_tok(x) for x in w)
-                for (B, S), w in zip(generator.fill_shapes, generator.fill_widths))
+    # the same two prices as the train leg: "algorithmic" = every batch at the width generate.py pads it to (its longest
+    # row + 2, generate.py:93-95); "executed" = every row at its own length, which is what the packed passes launch
+    flops_pad = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
+    flops_exec = sum(B * S * f_gen_tok(S) if w is None else sum(x * f_gen_tok(x) for x in w)
+                     for (B, S), w in zip(generator.fill_shapes, generator.fill_widths))
+    roofline = None
+    if variants:
+        d = variants[0]
+        roofline = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2), "peak": MFMA_PEAK_BF16 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(d["tflops"] * 1e12 / MFMA_PEAK_BF16, 4), "traffic": None,
+                    "avg_launch_us": round(d["avg_us"], 2), "sampled_launches": d["sampled_launches"],
+                    "gemm_launches_total": int(nl.value)}
     return {"value": round(world * n / dt, 3), "unit": "sequences/s", "sequences_per_rank": n, "batch": bs, "seconds": round(dt, 4),
-            "mean_len": round(sum(len(s) for s in seqs) / len(seqs), 1), "step_mfma_frac": round(flops / dt / MFMA_PEAK_BF16, 4),
+            "mean_len": round(sum(len(s) for s in seqs) / len(seqs), 1),
+            "step_mfma_frac": round(flops_pad / dt / MFMA_PEAK_BF16, 4),
+            "step_mfma_frac_executed": round(flops_exec / dt / MFMA_PEAK_BF16, 4),
+            "roofline": roofline,
             "workload": "configs[3]-style mass generation (generate.py full mode), lengths uniform %d..%d, 10 fill iterations"
                         % (pool[0], pool[-1])}
 
 
 def bench_generate(args, pg, generator, pool, rng, rank, world, dev):
     """Generated sequences/s of generate.py's full mode (batch 64 per GPU, lengths from the pool)."""
-    g = time_generate(pg, generator, pool, rank, world, dev, args.steps, args.warmup)
+    g = time_generate(pg, generator, pool, rank, world, dev, args.steps, args.warmup, profile_sample=args.profile_sample)
     out = {"metric": "generated sequences/s (generate.py full mode)", "value": g["value"], "unit": "sequences/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(g["seconds"] / max(1, args.steps) * 1e3, 2),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": g["workload"] + ", batch 64 per GPU", "sequences_per_rank": g["sequences_per_rank"],
                       "parallelism": f"shard{world}"},
-           "mean_len": g["mean_len"], "step_mfma_frac": g["step_mfma_frac"]}
+           "mean_len": g["mean_len"], "step_mfma_frac": g["step_mfma_frac"],
+           "step_mfma_frac_executed": g["step_mfma_frac_executed"], "roofline": g["roofline"]}
     if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, None, dev, generate_only=True)["generate"]
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(args, pg=None, dev=None):
+def cpu_baseline(args, pg=None, dev=None, generate_only=False):
     """The CPU oracle (a plain-PyTorch fp32 restatement of the reference path) timed on this
-    box's host cores on a bounded sample: one fill iteration and one critic update (GP double
-    backward + real + fake + backward + AdamW) at batch 2, len 512, full-size ProtBERT (about 10 s
-    of CPU work on 16 threads); the GAN step time is composed linearly in batch and iteration counts."""
+    box's host cores on a bounded sample, one warm-up and the median of three each:
+      * one fill iteration of generate.py's full mode at batch 4, L 510 (S 512) -> generated sequences/s
+        (ten iterations per sequence, generate.py:144-158);
+      * one critic update (GP double backward + real + fake + backward + AdamW) at batch 2, len 512;
+        the GAN step time is composed linearly in batch and iteration counts.
+    Full-size ProtBERT; about 40 s of CPU work on 16 threads."""
     from oracle import protbert_cpu as O
     torch.set_num_threads(min(torch.get_num_threads(), os.cpu_count() or 1))
     cores = torch.get_num_threads()
@@ -315,25 +406,43 @@ def cpu_baseline(args, pg=None, dev=None):
     C = O.init_classifier(c.hidden_size, seed=2)
     g = torch.Generator().manual_seed(0)
     S = args.seq
-    Bs = 2  # sample batch; times below are per sequence
-    ids, attn = O.build_fully_masked_batch([S - 2] * Bs)
-    noise = O.draw_noise(Bs * S, c.vocab_size, g)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        O.generate_step(P, c, ids, attn, 1.0, 0.1, 1.0, noise)
-    t_fill = (time.perf_counter() - t0) / Bs
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    Bf = 4  # configs[0]: batch 4, L 510
+    ids, attn = O.build_fully_masked_batch([S - 2] * Bf)
+    noise = O.draw_noise(Bf * S, c.vocab_size, g)
+    t_iter = []
+    for rep in range(4):  # the first is the warm-up
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.generate_step(P, c, ids.clone(), attn, 1.0, 0.1, 1.0, noise)
+        t_iter.append(time.perf_counter() - t0)
+    t_iter = t_iter[1:]
+    t_fill = med(t_iter) / Bf  # per sequence and iteration
+    gen_cpu = {"value": round(1.0 / (10 * t_fill), 5), "unit": "sequences/s", "cores": cores, "kind": "port",
+               "sample": (f"oracle/protbert_cpu.py fp32 on {cores} host threads: one fill iteration of generate.py's full mode at "
+                          f"batch {Bf}, L {S - 2} (S {S}), warm-up + median of 3 ({', '.join(f'{v:.2f}' for v in t_iter)} s); a "
+                          f"sequence takes ten iterations")}
+    if generate_only:
+        return {"generate": gen_cpu}
+    Bs = 2  # sample batch of the critic update; times below are per sequence
     real = torch.randint(5, 25, (Bs, S), generator=g)
     fake = torch.randint(5, 25, (Bs, S), generator=g)
     ones = torch.ones(Bs, S, dtype=torch.long)
     alpha = torch.rand(Bs, 1, 1, generator=g)
-    t0 = time.perf_counter()
-    loss, gp, rs, fs, grads = O.critic_step_grads(P, C, c, real, fake, ones, ones, alpha, args.lambda_gp)
+    t_updates = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        loss, gp, rs, fs, grads = O.critic_step_grads(P, C, c, real, fake, ones, ones, alpha, args.lambda_gp)
+        t_updates.append(time.perf_counter() - t0)
     k = "protbert.bert.encoder.layer.0.output.dense.weight"
     p, gr = P[k[len("protbert."):]].clone(), grads[k]
-    t1 = time.perf_counter()
-    O.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, 5e-5)
-    t_adam = (time.perf_counter() - t1) * (420.6e6 / p.numel())
-    t_bwd = t1 - t0                      # Bs sequences through GP + real + fake + backward
+    t_adams = []
+    for rep in range(3):
+        t1 = time.perf_counter()
+        O.adamw_step(p, gr, torch.zeros_like(p), torch.zeros_like(p), 1, 5e-5)
+        t_adams.append((time.perf_counter() - t1) * (420.6e6 / p.numel()))
+    t_adam = med(t_adams)
+    t_bwd = med(t_updates)               # Bs sequences through GP + real + fake + backward
     t_critic = t_bwd / Bs + t_adam / args.batch  # per sequence of a batch-`batch` update (one AdamW step per update)
     t_step = args.n_critic * (args.batch * t_critic + 10 * args.batch * t_fill) + (10 * args.gen_batch * t_fill + args.gen_batch * t_critic / 4)
     probe = None
@@ -358,8 +467,11 @@ def cpu_baseline(args, pg=None, dev=None):
                  "scores_max_abs_err": float((sc_h - sc).abs().max()), "scores_max_abs": float(sc.abs().max())}
         del critic
     return {"value": round(1.0 / t_step, 6), "unit": "GAN steps/s", "cores": cores, "kind": "port", "parity_probe": probe,
-            "sample": (f"oracle/protbert_cpu.py fp32 on {cores} host threads: 1 fill iteration B={Bs} S={S} ({t_fill:.2f} s/seq) + 1 critic "
-                       f"update B={Bs} S={S} incl. GP double backward ({t_bwd:.2f} s) and AdamW ({t_adam:.2f} s/step); per sequence "
+            "generate": gen_cpu,
+            "sample": (f"oracle/protbert_cpu.py fp32 on {cores} host threads, medians of 3: 1 fill iteration B={Bf} S={S} "
+                       f"({t_fill:.2f} s/seq) + 1 critic "
+                       f"update B={Bs} S={S} incl. GP double backward ({t_bwd:.2f} s; runs {', '.join(f'{v:.1f}' for v in t_updates)}) "
+                       f"and AdamW ({t_adam:.2f} s/step); per sequence "
                        f"{t_critic:.2f} s; GAN step composed as "
                        f"n_critic*(B*critic + 10*B*fill) + (10*Bg*fill + Bg*critic/4) = {t_step:.0f} s")}
 

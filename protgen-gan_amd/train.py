@@ -33,6 +33,17 @@ ONE_BACKWARD_DEFAULT = os.environ.get("PG_ONE_BACKWARD", "1") != "0"
 RAGGED_DEFAULT = os.environ.get("PG_RAGGED", "1") != "0"
 
 
+# Throughput bookkeeping: the sequence lengths every update actually ran, appended as
+# (kind, lengths of the gradient-penalty interpolates, lengths of the scored rows).  A benchmark clears the list,
+# runs, and prices the executed work from it; nothing in the training path reads it.
+EXEC_LOG: list = []
+
+
+def _note_rows(kind: str, gp_lens, score_lens):
+    if len(EXEC_LOG) < 1 << 20:
+        EXEC_LOG.append((kind, [int(v) for v in gp_lens], [int(v) for v in score_lens]))
+
+
 @dataclass
 class GanHyper:
     n_critic: int = 8                   # fully_masked_train.py:21
@@ -265,6 +276,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
                                          fake_mask.to(torch.float32), joint, lens_j, lens_rf[:B], lens_rf[B:], hp, grad_sync,
                                          alpha, train_encoder)
     mask3 = torch.cat([joint, rmask.to(torch.float32), fake_mask.to(torch.float32)], dim=0).contiguous()
+    _note_rows("critic", [S] * B, [S] * (2 * B))
 
     # embeddings of both batches straight into their rows of the 3B input, interpolates into the first B
     X = torch.empty(3 * B, S, H, dtype=cd, device=dev)
@@ -360,6 +372,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     st = ops.stream()
     dev = real.device
     lam = float(hp.lambda_gp)
+    _note_rows("critic", lens_j, list(lens_r) + list(lens_f))
     rg3 = Ragged(list(lens_j) + list(lens_r) + list(lens_f), S, dev)
     rgJ = Ragged(lens_j, S, dev)
     rgRF = Ragged(list(lens_r) + list(lens_f), S, dev)
@@ -485,6 +498,7 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
         return _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha,
                                           ragged, real_lengths, fake_lengths)
     critic_optimizer.zero_grad()
+    _note_rows("critic", [real_data.size(1)] * real_data.size(0), [real_data.size(1)] * (2 * real_data.size(0)))
     gp = compute_gradient_penalty(critic, real_data, fake, attn_mask_real, fake_mask, real_data.device, alpha=alpha)
     # real and fake rows go through the encoder as one 2B-row batch (rows are independent, so the
     # scores equal those of two separate calls); the larger GEMMs fill the chip better
@@ -513,6 +527,7 @@ def _generator_scores_ragged(critic: Critic, fake, fake_mask, lens) -> torch.Ten
     st = ops.stream()
     dev = fake.device
     train_encoder = m.encoder_trainable()
+    _note_rows("generator", [], lens)
     rg = Ragged(list(lens), S, dev)
     T = rg.T
     ids_p = rg.pack(fake).contiguous()
@@ -566,6 +581,7 @@ def generator_update(critic: Critic, gen_optimizer, fake_data, pad_id=0, fake_le
             g_loss = _generator_scores_ragged(critic, fk, fake_mask, lens)
             gen_optimizer.step()
             return g_loss.detach()
+    _note_rows("generator", [], [S] * fake.shape[0])
     fake_scores = critic(fake_data, attention_mask=(fake_data != pad_id).long())
     g_loss = generator_loss(fake_scores)
     g_loss.backward()

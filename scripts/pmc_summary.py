@@ -2,7 +2,7 @@
 scripts/pmc_gemm.py and the shape list that program printed; writes per shape the fabric-side bytes per launch.
 FETCH_SIZE is reported in KiB and, on gfx950, counts a 128-byte read request as 64 bytes: it is doubled here.
 WRITE_SIZE (KiB) is taken as reported.  usage: pmc_summary.py <fetch dir> <write dir> <shapes.json> <out.json>"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
 
 
 def per_dispatch(d, counter):
@@ -44,7 +44,17 @@ for s in shapes:
               "fetch_over_operands": round((f[1] + f[2]) / 2 / s["read_bytes"], 2),
               "write_over_output": round((w[1] + w[2]) / 2 / s["write_bytes"], 2)})
     out.append(s)
-json.dump({"note": "fabric-side bytes per call (all launches of the call), rocprofv3 --pmc FETCH_SIZE x2 (gfx950 counts a "
+def gemm_source_digest():
+    """Digest of the GEMM kernel sources the capture was taken on (bench.py quotes a capture only while it matches)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "protgen-gan_amd", "csrc", "gemm*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+json.dump({"gemm_source_digest": gemm_source_digest(), "note": "fabric-side bytes per call (all launches of the call), rocprofv3 --pmc FETCH_SIZE x2 (gfx950 counts a "
                    "128-byte request as 64) and WRITE_SIZE, separate passes", "shapes": out}, open(sys.argv[4], "w"), indent=1)
 for s in out:
     print(f"{s['shape']:10s} M{s['M']} N{s['N']} K{s['K']}: fetch {s['fetch_bytes_median']/1e6:8.1f} MB = {s['fetch_over_operands']:.2f} x operands "
