@@ -126,7 +126,10 @@ def main():
     sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world, overlap=critic.protbert,
                         position_rows=args.seq)
 
-    rng = random.Random(1234 + rank)
+    # lengths (real rows and fake templates) come from one stream every rank seeds alike: a rank draws the global
+    # batch's lengths and keeps its balanced share (data.balanced_deal), so the ranks' token counts stay within a few
+    # per cent of each other and none is the straggler of every gradient reduction; contents are per rank
+    rng = random.Random(1234)
     torch.manual_seed(1234 + rank)
     tgen = torch.Generator().manual_seed(1234 + rank)
     scale = args.seq / 512.0
@@ -136,7 +139,7 @@ def main():
         return bench_generate(args, pg, generator, pool, rng, rank, world, dev)
 
     total = args.warmup + args.steps
-    real = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic)]
+    real = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen, rank, world) for _ in range(args.n_critic)]
             for _ in range(total)]
 
     use_sync = world > 1
@@ -151,7 +154,7 @@ def main():
 
     seeds = None
     if args.gan_mode == "seeded":
-        seeds = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen) for _ in range(args.n_critic + 1)]
+        seeds = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen, rank, world) for _ in range(args.n_critic + 1)]
                  for _ in range(total)]
 
     soft = args.soft_generator_update
@@ -164,7 +167,8 @@ def main():
             return pgt.gan_step_seeded(generator, critic, gen_opt, critic_opt, real[i], seeds[i], hp,
                                        grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
-                                  grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
+                                  grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync,
+                                  rank=rank, world=world)
 
     def fence():
         if world > 1:

@@ -61,17 +61,59 @@ class TokenizedSet:
                 "lengths": [self.lengths[i] for i in idx.tolist()]}
 
 
+def balanced_deal(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Deals the rows of one global batch to `world` ranks so that every rank gets the same number of rows and
+    nearly the same number of tokens: rows sorted by length, longest first, handed out in rounds of `world` whose
+    direction alternates (0..world-1, then world-1..0, ...), then single rows traded between the fullest and the
+    emptiest rank while that helps.  Deterministic: every rank computes the same deal from the same lengths.  Returns, per rank, the indices into `lengths` it
+    receives.  Which rank holds which row does not change the averaged gradient (the losses are batch means over
+    rows of equal weight, loss.py:4,95); it changes how long the slowest rank of a step takes, since every rank
+    waits for that one at each gradient reduction.  len(lengths) must be a multiple of world."""
+    n = len(lengths)
+    if world <= 0 or n % world:
+        raise ValueError(f"{n} rows cannot be dealt evenly to {world} ranks")
+    order = sorted(range(n), key=lambda i: (-int(lengths[i]), i))
+    out: List[List[int]] = [[] for _ in range(world)]
+    for rnd in range(n // world):
+        chunk = order[rnd * world:(rnd + 1) * world]
+        if rnd % 2:
+            chunk = chunk[::-1]
+        for r, i in enumerate(chunk):
+            out[r].append(i)
+    # then trade single rows between the fullest and the emptiest rank while that narrows the gap between them
+    sums = [sum(int(lengths[i]) for i in rows) for rows in out]
+    for _ in range(4 * n):
+        hi = max(range(world), key=lambda r: (sums[r], r))
+        lo = min(range(world), key=lambda r: (sums[r], r))
+        gap = sums[hi] - sums[lo]
+        best = None
+        for a, i in enumerate(out[hi]):
+            for b, j in enumerate(out[lo]):
+                d = int(lengths[i]) - int(lengths[j])
+                if 0 < d < gap and (best is None or abs(gap - 2 * d) < best[0]):
+                    best = (abs(gap - 2 * d), a, b, d)
+        if best is None or best[0] >= gap:
+            break
+        _, a, b, d = best
+        out[hi][a], out[lo][b] = out[lo][b], out[hi][a]
+        sums[hi] -= d
+        sums[lo] += d
+    return out
+
+
 class BatchLoader:
     """Batches of `batch_size` rows of `data` over the row indices `subset` (all rows by default), reshuffled on every
     `iter()` from `generator` (a CPU torch.Generator; the global one if None), incomplete last batch dropped.  With
-    world > 1 a global batch is world * batch_size rows and this rank gets rows rank, rank + world, ... of it, so
-    every rank builds the same permutation (same generator seed) and no two ranks see the same row."""
+    world > 1 a global batch is world * batch_size rows of the permutation every rank builds alike (same generator
+    seed), and no two ranks see the same row: with `balance` (default) the global batch is dealt by length
+    (balanced_deal), so the ranks' token counts stay within a few per cent of each other; without it this rank gets
+    rows rank, rank + world, ... of the global batch."""
 
     def __init__(self, data: TokenizedSet, batch_size: int, device, subset: Optional[Sequence[int]] = None,
-                 generator: Optional[torch.Generator] = None, rank: int = 0, world: int = 1):
+                 generator: Optional[torch.Generator] = None, rank: int = 0, world: int = 1, balance: bool = True):
         self.data, self.batch_size, self.device = data, batch_size, device
         self.subset = list(range(len(data))) if subset is None else list(subset)
-        self.generator, self.rank, self.world = generator, rank, world
+        self.generator, self.rank, self.world, self.balance = generator, rank, world, balance
 
     def __len__(self):
         return len(self.subset) // (self.batch_size * self.world)
@@ -80,6 +122,11 @@ class BatchLoader:
         perm = torch.randperm(len(self.subset), generator=self.generator).tolist()
         g = self.batch_size * self.world
         for b in range(len(self)):
+            if self.world > 1 and self.balance:
+                glob = [self.subset[r] for r in perm[b * g:(b + 1) * g]]
+                mine = balanced_deal([self.data.lengths[i] for i in glob], self.world)[self.rank]
+                yield self.data.batch([glob[i] for i in mine], self.device)
+                continue
             rows = perm[b * g + self.rank:(b + 1) * g:self.world]
             yield self.data.batch([self.subset[r] for r in rows], self.device)
 

@@ -39,6 +39,12 @@ RAGGED_DEFAULT = os.environ.get("PG_RAGGED", "1") != "0"
 EXEC_LOG: list = []
 
 
+# Diagnostics only: called with the critic head's stash ([3B][pg_head_stash_floats] fp32: input copy, the three
+# post-ReLU activations, backward vectors) right after the head's forward of a one-forward critic update, before
+# any backward reads it.  A precision experiment records one run's ReLU gates here and imposes them on another's.
+HEAD_STASH_HOOK = None
+
+
 def _note_rows(kind: str, gp_lens, score_lens):
     if len(EXEC_LOG) < 1 << 20:
         EXEC_LOG.append((kind, [int(v) for v in gp_lens], [int(v) for v in score_lens]))
@@ -64,6 +70,18 @@ def sample_sequence_length(length_pool: Sequence[int], variation: float = 0.1, r
     return min(500, max(1, base + rng.randint(-var, var)))
 
 
+def sample_fake_lengths(length_pool: Sequence[int], batch_size: int, rng=random, rank: int = 0, world: int = 1) -> List[int]:
+    """The template lengths (CLS and SEP included) of one blind-mode fake batch (fully_masked_train.py:203-207).
+    world > 1: `rng` must be seeded alike on every rank; the lengths of the world * batch_size rows of the global
+    fake batch are drawn from it and dealt by length (data.balanced_deal), so every rank fills and scores about the
+    same number of tokens and no rank is the one the others wait for at each gradient reduction."""
+    if world <= 1:
+        return [sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size)]
+    from .data import balanced_deal
+    glob = [sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size * world)]
+    return [glob[i] for i in balanced_deal(glob, world)[rank]]
+
+
 def freeze_protbert(model, freeze: bool = True):
     """fully_masked_train.py:119-121."""
     for p in model.protbert.parameters():
@@ -71,11 +89,13 @@ def freeze_protbert(model, freeze: bool = True):
 
 
 def generate_fake_batch(generator: Generator, batch_size_local: int, length_pool: Sequence[int], hp: GanHyper,
-                        device, rng=random, mask_id=4, cls_id=2, sep_id=3, pad_id=0) -> torch.Tensor:
+                        device, rng=random, mask_id=4, cls_id=2, sep_id=3, pad_id=0,
+                        lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Blind mode (fully_masked_train.py:195-258): fully masked templates of sampled lengths,
     attention mask `ids != MASK` recomputed every iteration, per-iteration temperature, then
     pad / truncate to max_len.  The template is assembled on the host and copied once."""
-    lengths = [sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size_local)]
+    if lengths is None:
+        lengths = [sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size_local)]
     S = max(lengths)
     ids = torch.full((batch_size_local, S), pad_id, dtype=torch.long)
     for i, L in enumerate(lengths):
@@ -292,6 +312,8 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
     check(lib.pg_head_forward(dt, hidden.data_ptr(), S * H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
                               hstash.data_ptr(), st), "pg_head_forward")
+    if HEAD_STASH_HOOK is not None:
+        HEAD_STASH_HOOK(hstash)
     m.store.begin_accumulate()
     head.store.begin_accumulate()
     ghead = head.store.grad
@@ -397,6 +419,8 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
     check(lib.pg_head_forward(dt, cls.data_ptr(), H, head.store.master.data_ptr(), 3 * B, H, scores.data_ptr(),
                               hstash.data_ptr(), st), "pg_head_forward")
+    if HEAD_STASH_HOOK is not None:
+        HEAD_STASH_HOOK(hstash)
     if train_encoder:
         m.store.begin_accumulate()
     head.store.begin_accumulate()
@@ -649,7 +673,7 @@ def blind_template(lengths: Sequence[int], device, mask_id=4, cls_id=2, sep_id=3
 def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                    real_batches: List[dict], length_pool: Sequence[int], hp: GanHyper, batch_size: int, device,
                    rng=random, grad_sync=None, stacked_generation: bool = True, soft_generator_update: bool = False,
-                   gen_grad_sync=None):
+                   gen_grad_sync=None, rank: int = 0, world: int = 1):
     """One iteration of the blind-mode training loop: n_critic critic updates (each with a
     fresh fake batch) followed by one generator update on `gen_batch_blind` fakes.
 
@@ -658,6 +682,9 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     up front as one stacked batch.  The host random draws are made in the order the
     one-after-the-other loop makes them (lengths from `rng`; temperatures and the
     gradient-penalty alpha from the CPU torch generator).
+
+    `rank`, `world` (data-parallel, stacked form): `rng` is then the generator all ranks seed alike, and the fake
+    lengths are this rank's balanced share of the global draw (sample_fake_lengths).
 
     `soft_generator_update`: the generator update is generator_update_soft on the fully masked template of the
     generator batch (keys visible as in the fill: `ids != MASK`; the critic sees `ids != PAD`), at the first
@@ -669,19 +696,21 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     if not stacked_generation:
         c_sum = None
         for batch in real_batches:
-            fake = generate_fake_batch(generator, batch_size, length_pool, hp, device, rng=rng)
+            fake = generate_fake_batch(generator, batch_size, length_pool, hp, device, rng=rng,
+                                       lengths=sample_fake_lengths(length_pool, batch_size, rng, rank, world))
             c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
                               grad_sync=grad_sync)
             c_sum = c if c_sum is None else c_sum + c
-        fake = generate_fake_batch(generator, hp.gen_batch_blind, length_pool, hp, device, rng=rng)
+        fake = generate_fake_batch(generator, hp.gen_batch_blind, length_pool, hp, device, rng=rng,
+                                   lengths=sample_fake_lengths(length_pool, hp.gen_batch_blind, rng, rank, world))
         g = generator_update(critic, gen_optimizer, fake)
         return c_sum / hp.n_critic, g
     lengths, temps, alphas = [], [], []
     for batch in real_batches:
-        lengths.append([sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(batch_size)])
+        lengths.append(sample_fake_lengths(length_pool, batch_size, rng, rank, world))
         temps.append(fill_temperatures(hp))
         alphas.append(torch.rand(batch["input_ids"].size(0), 1, 1))
-    lengths.append([sample_sequence_length(length_pool, rng=rng) + 2 for _ in range(hp.gen_batch_blind)])
+    lengths.append(sample_fake_lengths(length_pool, hp.gen_batch_blind, rng, rank, world))
     temps.append(fill_temperatures(hp))
     n_fill = len(lengths) - (1 if soft_generator_update else 0)
     fakes = generate_fake_batches(generator, lengths[:n_fill], temps[:n_fill], hp, device)
@@ -771,15 +800,21 @@ def generate_eval_sequences(generator: Generator, tokenizer, num_sequences: int,
 
 
 def synthetic_real_batch(batch_size: int, length_pool: Sequence[int], max_len: int, device, rng: random.Random,
-                         gen: torch.Generator):
+                         gen: torch.Generator, rank: int = 0, world: int = 1):
     """A dataset.py-shaped batch (ids [B,max_len] int64, attention_mask [B,max_len] float) of
     i.i.d. residues (ids 5..24) with lengths from the pool: the stand-in for the DNMT set,
-    which is not distributed with the reference."""
+    which is not distributed with the reference.  world > 1: `rng` is seeded alike on every rank, draws the
+    lengths of the global batch, and this rank keeps its balanced share (data.balanced_deal), as a BatchLoader
+    does with real data; the residues come from `gen`, which each rank seeds for itself."""
     ids = torch.zeros(batch_size, max_len, dtype=torch.long)
     mask = torch.zeros(batch_size, max_len, dtype=torch.float32)
     lengths = []
+    drawn = [min(rng.choice(length_pool), max_len - 2) for _ in range(batch_size * max(1, world))]
+    if world > 1:
+        from .data import balanced_deal
+        drawn = [drawn[i] for i in balanced_deal(drawn, world)[rank]]
     for b in range(batch_size):
-        L = min(rng.choice(length_pool), max_len - 2)
+        L = drawn[b]
         ids[b, 0] = 2
         ids[b, 1:L + 1] = torch.randint(5, 25, (L,), generator=gen)
         ids[b, L + 1] = 3

@@ -145,7 +145,7 @@ def fit(steps: Steps, mode: str, n_epochs: int, lr_critic: float, first_epoch: i
 # ----------------------------------------------------------------------------- the engine behind the interface
 class EngineSteps(Steps):
     def __init__(self, pg, args, generator, critic, gen_opt, critic_opt, data, pool, tokenizer, device, rank, world,
-                 grad_sync, log=print, gen_grad_sync=None):
+                 grad_sync, log=print, gen_grad_sync=None, first_epoch=0):
         from . import train as T
         self.pg, self.T, self.args = pg, T, args
         self.generator, self.critic, self.gen_opt, self.critic_opt = generator, critic, gen_opt, critic_opt
@@ -153,11 +153,19 @@ class EngineSteps(Steps):
         self.rank, self.world, self.grad_sync, self.log = rank, world, grad_sync, log
         self.gen_grad_sync = gen_grad_sync
         self.soft = bool(getattr(args, "soft_generator_update", False))
+        self.stacked = not bool(getattr(args, "reference_draw_order", False))
+        if self.soft and not self.stacked:
+            raise ValueError("--soft_generator_update needs the stacked fill: drop --reference_draw_order")
         self.n_critic = args.n_critic
         self.hp = T.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.max_len,
                              gen_batch_blind=GEN_BATCH_BLIND)
-        self.py_rng = random.Random(args.seed + rank)
-        self.data_rng = torch.Generator().manual_seed(args.seed)  # the same on every rank: ranks share one permutation
+        # a resumed run continues with streams of its own (the epoch it starts at is folded into every seed): seeded
+        # from args.seed alone it would replay the first epoch's permutations and length draws
+        salt = 7919 * first_epoch
+        self.py_rng = random.Random(args.seed + salt + rank)
+        # the same on every rank: ranks share one permutation of the data and one draw of the global fake lengths
+        self.data_rng = torch.Generator().manual_seed(args.seed + salt)
+        self.len_rng = random.Random(args.seed + salt) if world > 1 else self.py_rng
         self.updates, self.t0 = 0, time.perf_counter()
 
     def set_frozen(self, frozen):
@@ -184,13 +192,14 @@ class EngineSteps(Steps):
         T, hp = self.T, self.hp
         if with_generator_update:
             c, g = T.gan_step_blind(self.generator, self.critic, self.gen_opt, self.critic_opt, list(real_batches), self.pool,
-                                    hp, self.args.batch_size, self.device, rng=self.py_rng, grad_sync=self._sync(),
+                                    hp, self.args.batch_size, self.device, rng=self.len_rng, grad_sync=self._sync(),
                                     soft_generator_update=self.soft,
-                                    gen_grad_sync=self.gen_grad_sync if self.world > 1 else None)
+                                    gen_grad_sync=self.gen_grad_sync if self.world > 1 else None,
+                                    rank=self.rank, world=self.world, stacked_generation=self.stacked)
             self.updates += len(real_batches)
             return float(c), float(g)
         # the incomplete last group of an epoch: its critic updates only
-        lengths = [[T.sample_sequence_length(self.pool, rng=self.py_rng) + 2 for _ in range(self.args.batch_size)]
+        lengths = [T.sample_fake_lengths(self.pool, self.args.batch_size, self.len_rng, self.rank, self.world)
                    for _ in real_batches]
         temps = [T.fill_temperatures(hp) for _ in real_batches]
         fakes = T.generate_fake_batches(self.generator, lengths, temps, hp, self.device)
@@ -206,7 +215,7 @@ class EngineSteps(Steps):
         if n == hp.n_critic and gen_update_batch is not None:
             c, g = T.gan_step_seeded(self.generator, self.critic, self.gen_opt, self.critic_opt, list(real_batches),
                                      list(gen_batches) + [gen_update_batch], hp, grad_sync=self._sync(),
-                                     soft_generator_update=self.soft,
+                                     soft_generator_update=self.soft, stacked_generation=self.stacked,
                                      gen_grad_sync=self.gen_grad_sync if self.world > 1 else None)
             self.updates += n
             return float(c), float(g)
@@ -272,6 +281,11 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--resume", default=None, help="an epoch_<n> checkpoint directory of a previous run")
+    ap.add_argument("--reference_draw_order", action="store_true",
+                    help="fill each fake batch right before the update that uses it, as the reference loop does, so the CPU "
+                         "generator hands out temperatures and gradient-penalty alphas in the reference's order.  The default "
+                         "fills all fake batches of an iteration as one stacked batch (faster, same tokens per batch on the "
+                         "same noise) and therefore draws every temperature of the iteration before its first alpha")
     ap.add_argument("--no_optimizer_state", action="store_true", help="checkpoints as the reference writes them (weights only)")
     ap.add_argument("--soft_generator_update", action="store_true",
                     help="generator update through soft embeddings and the critic's 3-D branch (gradients reach the generator) "
@@ -293,8 +307,6 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(args.seed + rank)
-
     first_epoch = 0
     if args.resume:
         gen_dir, critic_dir = os.path.join(args.resume, "generator_bert"), os.path.join(args.resume, "critic_bert")
@@ -302,6 +314,7 @@ def main(argv=None):
             first_epoch = int(json.load(fh)["epoch"])
     else:
         gen_dir = critic_dir = args.model_dir
+    torch.manual_seed(args.seed + 7919 * first_epoch + rank)
     if args.init_random and not args.resume:
         cfg = pg.ProtBertConfig(num_hidden_layers=args.layers)
         gen_bert = pg.ProtBertForMaskedLM(cfg, device=device, compute_dtype=dtype).init_random(seed=0)
@@ -335,7 +348,7 @@ def main(argv=None):
     if args.soft_generator_update:
         gen_sync = pgd.GradSync([generator.protbert.store], world, overlap=generator.protbert, position_rows=args.max_len)
     steps = EngineSteps(pg, args, generator, critic, gen_opt, critic_opt, data, pool, tokenizer, device, rank, world, sync,
-                        log=lambda s: print(s, flush=True), gen_grad_sync=gen_sync)
+                        log=lambda s: print(s, flush=True), gen_grad_sync=gen_sync, first_epoch=first_epoch)
     if rank == 0:
         print(f"{args.mode} mode, {len(data)} sequences, {world} GPU(s), batch {args.batch_size} per GPU, epochs "
               f"{first_epoch + 1}..{args.n_epochs}", flush=True)

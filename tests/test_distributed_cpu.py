@@ -65,6 +65,30 @@ def _worker(rank, world, port, q):
         _, _, _, _, full = O.critic_step_grads(P, C, cfg, real, fake, ones, ones, alpha, 5.0)
         err = max(float((p.grad - full[n]).abs().max() / (full[n].abs().max() + 1e-12)) for p, n in zip(params, names))
         q.put(("grad_err", err))
+    # the same identity when the rows of the global batch are dealt by length instead of cut in order: lengths 16, 8,
+    # 12, 4 -> rank 0 holds rows {0, 3}, rank 1 rows {1, 2}; each row keeps its own alpha
+    from protgen_gan_amd import data as DD
+    lens = [16, 8, 12, 4]
+    rm = torch.zeros(B, S, dtype=torch.long)
+    real2, fake2 = real.clone(), fake.clone()
+    for b, n in enumerate(lens):
+        rm[b, :n] = 1
+        real2[b, n:] = O.PAD
+        fake2[b, n:] = O.PAD
+    mine = DD.balanced_deal(lens, world)[rank]
+    tok = sum(lens[i] for i in mine)
+    idx = torch.tensor(mine)
+    _, _, _, _, grads = O.critic_step_grads(P, C, cfg, real2[idx], fake2[idx], rm[idx], rm[idx], alpha[idx], 5.0)
+    for p, n in zip(params, names):
+        p.grad.copy_(grads[n])
+    D.GradSync([store], world, bucket_bytes=4096)()
+    toks = [None] * world
+    dist.all_gather_object(toks, (sorted(mine), tok))
+    if rank == 0:
+        _, _, _, _, full = O.critic_step_grads(P, C, cfg, real2, fake2, rm, rm, alpha, 5.0)
+        err = max(float((p.grad - full[n]).abs().max() / (full[n].abs().max() + 1e-12)) for p, n in zip(params, names))
+        q.put(("dealt_grad_err", err))
+        q.put(("dealt", toks))
     # sharded generation bookkeeping: every index exactly once, per-rank seeds differ
     got = D.generate_sharded(lambda num_sequences, rng_seed: [f"{rng_seed}:{i}" for i in range(num_sequences)], 7, rank,
                              world, rng_seed=100)
@@ -82,11 +106,13 @@ def test_grad_sync_and_sharding_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = dict(q.get(timeout=240) for _ in range(2))
+    out = dict(q.get(timeout=240) for _ in range(4))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out["grad_err"] < 1e-5  # mean of per-shard gradients == global-batch gradient
+    assert out["dealt_grad_err"] < 1e-5  # ... whichever rank holds which row
+    assert out["dealt"] == [([0, 3], 20), ([1, 2], 20)]
     assert out["gathered"] == ["100:0", "100:1", "100:2", "100:3", "101:0", "101:1", "101:2"]
 
 
@@ -147,3 +173,144 @@ def test_layerwise_plan_order_and_coverage():
     for p, off, n in store.views[1:]:
         want[off:off + n] = 1
     assert torch.equal(seen, want)
+
+
+def test_balanced_deal_token_counts():
+    """data.balanced_deal on global batches of 8 rows per rank with the benchmark's lengths (uniform 200..500 + CLS/SEP):
+    every rank the same number of rows, every row exactly once, per-rank token counts within 2 % of each other
+    (dealing rows r, r + world, ... leaves them up to 50 % apart), the same deal on every rank."""
+    import random
+    pgload.load()
+    from protgen_gan_amd import data as DD
+    from protgen_gan_amd import train as T
+    for world in (2, 4, 8):
+        worst = naive = 0.0
+        for seed in range(200):
+            rng = random.Random(seed)
+            L = [rng.randint(200, 500) + 2 for _ in range(8 * world)]
+            deal = DD.balanced_deal(L, world)
+            assert deal == DD.balanced_deal(list(L), world)
+            assert sorted(i for d in deal for i in d) == list(range(8 * world)) and all(len(d) == 8 for d in deal)
+            sums = [sum(L[i] for i in d) for d in deal]
+            worst = max(worst, (max(sums) - min(sums)) / (sum(sums) / world))
+            strided = [sum(L[r::world]) for r in range(world)]
+            naive = max(naive, (max(strided) - min(strided)) / (sum(strided) / world))
+        assert worst < 0.02 < naive, (world, worst, naive)
+    with pytest.raises(ValueError):
+        DD.balanced_deal([5, 6, 7], 2)
+    # the trainers' draws: every rank seeds the length stream alike and keeps its share of the global draw
+    pool = list(range(200, 501))
+    shares = [T.sample_fake_lengths(pool, 8, random.Random(3), r, 4) for r in range(4)]
+    glob = [T.sample_sequence_length(pool, rng=rng) + 2 for rng in [random.Random(3)] for _ in range(32)]
+    assert sorted(v for s in shares for v in s) == sorted(glob)
+    sums = [sum(s) for s in shares]
+    assert (max(sums) - min(sums)) / (sum(sums) / 4) < 0.02
+    assert T.sample_fake_lengths(pool, 8, random.Random(3)) == glob[:8]  # one rank: the plain draw
+    g = torch.Generator().manual_seed(0)
+    parts = [T.synthetic_real_batch(8, pool, 512, "cpu", random.Random(5), g, r, 2) for r in range(2)]
+    tot = [sum(p["lengths"]) for p in parts]
+    assert abs(tot[0] - tot[1]) / (sum(tot) / 2) < 0.02
+    for p in parts:
+        assert p["attention_mask"].sum(dim=1).tolist() == [float(v) for v in p["lengths"]]
+
+
+def test_batch_loader_deals_global_batches():
+    """BatchLoader at world 2: both ranks walk the same permutation, never share a row, cover every global batch, and
+    (balance on) hold token counts within 2 % of each other per batch."""
+    pgload.load()
+    from protgen_gan_amd import data as DD
+    import random
+    rng = random.Random(0)
+    N, S = 64, 512
+    lengths = [rng.randint(200, 500) + 2 for _ in range(N)]
+    ids = torch.zeros(N, S, dtype=torch.long)
+    ids[:, 0] = torch.arange(N)  # row tag
+    mask = torch.zeros(N, S)
+    for i, n in enumerate(lengths):
+        mask[i, :n] = 1
+    data = DD.TokenizedSet(ids, mask, lengths)
+    for balance in (True, False):
+        loaders = [DD.BatchLoader(data, 8, "cpu", generator=torch.Generator().manual_seed(4), rank=r, world=2, balance=balance)
+                   for r in range(2)]
+        assert len(loaders[0]) == 4
+        seen = []
+        for b0, b1 in zip(*loaders):
+            r0, r1 = b0["input_ids"][:, 0].tolist(), b1["input_ids"][:, 0].tolist()
+            assert len(r0) == len(r1) == 8 and not set(r0) & set(r1)
+            seen += r0 + r1
+            if balance:
+                t0, t1 = sum(b0["lengths"]), sum(b1["lengths"])
+                assert abs(t0 - t1) / ((t0 + t1) / 2) < 0.02
+        assert sorted(seen) == list(range(N))
+
+
+def test_layerwise_plan_on_the_full_protbert_layout():
+    """GradSync's plan on ProtBERT's real parameter layout (30 layers x 1024, offsets from the library), positions
+    bounded at 512: one 50.4 MB bucket per layer, layers 29 -> 0, then the embedding tables and the head; the bytes on
+    the wire are the critic's reachable parameters minus the position rows no batch touches."""
+    import ctypes as C
+    pg = pgload.load()
+    from protgen_gan_amd import _lib, bert
+    from protgen_gan_amd import distributed as D
+    cfg = pg.ProtBertConfig()
+    ccfg = cfg.to_c()
+    lib = _lib.lib
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+
+    class Store:
+        def __init__(self, total):
+            self.grad = torch.empty(total, device="meta")
+            self.views, self.live_elems = [], {}
+
+        def add(self, off, shape):
+            p = torch.nn.Parameter(torch.empty(shape, device="meta"))
+            p.grad = torch.empty(shape, device="meta")
+            self.views.append((p, off, p.numel()))
+
+    store = Store(lib.pg_param_total(C.byref(ccfg)))
+    for name, which in bert._GLOBAL_NAMES:
+        if not name.startswith("cls."):  # the MLM head is not on the critic's path: no gradient, not reduced
+            store.add(lib.pg_param_offset_global(C.byref(ccfg), which), bert._shape_of(cfg, name))
+    spans = []
+    for l in range(L):
+        offs = []
+        for suffix, which in bert._LAYER_NAMES:
+            off = lib.pg_param_offset_layer(C.byref(ccfg), l, which)
+            shape = bert._shape_of(cfg, f"bert.encoder.layer.{l}.{suffix}")
+            store.add(off, shape)
+            offs.append((off, off + int(torch.Size(shape).numel())))
+        spans.append((min(a for a, _ in offs), max(b for _, b in offs)))
+    head = Store(lib.pg_head_total(H))
+    head.add(0, (lib.pg_head_total(H),))
+
+    class Model:
+        config = cfg
+
+        def __init__(self):
+            self.store = store
+
+        def enable_layer_events(self):
+            return []
+
+        def layer_param_range(self, l):
+            return spans[l]
+
+        def limit_position_rows(self, rows):
+            store.live_elems[lib.pg_param_offset_global(C.byref(ccfg), _lib.P_POS_EMB)] = rows * H
+
+    sync = D.GradSync([store, head], world=8, overlap=Model(), position_rows=512)
+    plan = sync._plan()
+    per_layer = 4 * H * H + 2 * H * I + 9 * H + I
+    assert per_layer == 12596224
+    layer_part = [(l, b - a) for l, st, a, b in plan if l is not None]
+    assert layer_part == [(l, per_layer) for l in reversed(range(L))]  # one bucket per layer (64 MiB holds 50.4 MB)
+    rest = [(st, a, b) for l, st, a, b in plan if l is None]
+    assert plan[:L] == [(l, st, a, b) for l, st, a, b in plan if l is not None]  # the layers come first
+    tables = sum(b - a for st, a, b in rest if st is store)
+    assert tables == cfg.vocab_size * H + 512 * H + cfg.type_vocab_size * H + 2 * H
+    assert sum(b - a for st, a, b in rest if st is head) == 672641
+    wire = 4 * (L * per_layer + tables + 672641)
+    reachable = 4 * (L * per_layer + cfg.vocab_size * H + cfg.max_position_embeddings * H + cfg.type_vocab_size * H + 2 * H
+                     + 672641)
+    assert reachable - wire == 4 * (cfg.max_position_embeddings - 512) * H  # 161.7 MB of zeros stay home
+    assert abs(wire / 1e9 - 1.5168) < 1e-3, wire
