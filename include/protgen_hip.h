@@ -121,12 +121,33 @@ int pg_gemm_pair(const pg_gemm_desc* d0, const pg_gemm_desc* d1, void* stream);
  * 325-351): none of them has enough 256x256 tiles to cover the chip alone; the encoder backward passes
  * collect those of up to four layers (192 tiles per layer at ProtBERT's sizes, 768 = three rounds of 256 CUs). */
 int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream);
+/* Test and measurement hook (no reference counterpart): sets one dispatch threshold or switch of the library.
+ * The settings are process-global and unsynchronised: call it from the thread that launches, never beside a launch.
+ * A product run never calls it; the defaults are the measured best.  Everything else in this header is free of
+ * hidden state: a call reads its arguments, launches on the given stream and keeps no pointer, so calls on different
+ * streams / devices from different threads are independent (pg_profile_* excepted, see above).
+ * key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never,
+ * 1 N<=64, 2 also grids of at most 256 128x128 tiles); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always);
+ * key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1); key 6: fused attention kernels
+ * in the gradient-penalty passes (0/1); key 7: two-segment products in one launch (0/1); key 8: tile rows per group of
+ * the grouped tile order (>= 1); key 9: a last round of 256x256 tiles less than this many per cent full sends its rows
+ * to a second launch (0 = never, default 50); key 10: smallest K at which a narrow-N product with >= 512 tiles takes
+ * the 256x256 kernel; key 11: pg_gemm_group in one launch (0/1); key 12: most row chunks of a pg_colsum_acc launch
+ * below 8192 rows (twice that from there on); key 13: layers whose weight gradients share one grouped launch (0 = by
+ * tile count, 1..4); key 14: fewest 256x256 tiles at which a product with 512 <= N < 2048 takes the 256x256 kernel
+ * (default 129); key 15: GELU backward inside the GEMM epilogue also in passes that keep adjoints (0/1); key 16:
+ * largest 128x128 grid (workgroups) that takes the four-buffer ring (default 256); key 17: waves per workgroup of a
+ * pg_colsum_acc launch (4 or 16); key 18 (precision experiments, fp32 passes only): bit mask of the stored quantities
+ * rounded to bf16 values at the end of every layer: 1 forward token-row slots, 2 attention probabilities, 4 adjoint
+ * token-row slots of a backward that keeps adjoints, 8 adjoint scores, 16 tangent token-row slots, 32 tangent scores;
+ * key 20: inference passes walk the visible keys only (0/1, default 1); key 23: GEMM epilogues fetch their per-element
+ * operand several row blocks at a time (0/1, default 1).  Other keys: PG_ERR_ARG. */
+int pg_tune(int key, int value);
 /* Measurement aid (no reference counterpart): time every `sample_every`-th pg_gemm launch
  * with HIP events on its own stream.  pg_profile_end synchronises those events, stops the
  * sampling and fills out[16][3] = {launches sampled, FLOPs sampled, milliseconds} per kernel
  * variant, index 8*(bf16 inputs) + 4*(fp32 output) + 2*(a_kmajor) + b_kmajor.  Host state is
  * process-global and not thread-safe. */
-int pg_tune(int key, int value); /* key 0: bf16 GEMM path (0 register-staged, 1 direct-to-LDS auto, 2/4 ring depth); key 1: 128x64 tiles (0 never, 1 N<=64, 2 also small grids); key 2: 256x256 tiles (0 never, 1 large-N products, 2 always); key 4: 16-byte bf16 epilogue accesses (0/1); key 5: pg_gemm_pair in one launch (0/1); key 6: fused attention kernels in the gradient-penalty passes (0/1); key 7: two-segment products in one launch (0/1); key 8: tile rows per group of the grouped tile order (>= 1); key 9: a last round of 256x256 tiles less than this many per cent full sends its rows to a second launch (0 = never, default 50); key 10: smallest K at which a narrow-N product with >= 512 tiles takes the 256x256 kernel; key 11: pg_gemm_group in one launch (0/1); key 12: most row chunks of a pg_colsum_acc launch below 8192 rows (twice that from there on); key 13: layers whose weight gradients share one grouped launch (0 = by tile count, 1..4); key 14: fewest 256x256 tiles at which a product with 512 <= N < 2048 takes the 256x256 kernel (default 129: as soon as the 128x128 tiles no longer fit the chip at once); key 15: GELU backward inside the GEMM epilogue also in passes that keep adjoints (0/1); key 16: largest 128x128 grid (workgroups) that takes the four-buffer ring (default 256); key 17: waves per workgroup of a pg_colsum_acc launch (4 or 16); key 18 (precision experiments, fp32 passes only): bit mask of the stored quantities rounded to bf16 values at the end of every layer: 1 forward token-row slots, 2 attention probabilities, 4 adjoint token-row slots of a backward that keeps adjoints, 8 adjoint scores, 16 tangent token-row slots, 32 tangent scores; key 19: most 128x128 tiles of an unbatched bf16 product that takes 128x64 tiles instead (default 0 = never); key 20: inference passes walk the visible keys only (0/1, default 1); key 21: k-major x k-major products on 256x256 tiles take the five-slot ring kernel of 32-k half-stages (0/1, default 0; 2 = timing experiment without the in-loop loads, wrong results); key 22: bf16 outputs of at least this many MiB leave the GEMM epilogue with streaming stores (default 0 = never); key 23: GEMM epilogues fetch their per-element operand (pre-activation, residual or C) several row blocks at a time instead of one load per output chunk (0/1, default 1); key 24: 256x256-tile products with a k-major A and more tiles than workgroups run persistent workgroups that walk their tiles (0 = off, the default; 1 = one workgroup per CU; n > 1 = n workgroups) */
 int pg_profile_begin(int sample_every);
 int pg_profile_end(double* out, int64_t* total_launches);
 

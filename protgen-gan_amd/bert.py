@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import math
+import weakref
 import os
 from dataclasses import asdict, dataclass
 from typing import Dict, Optional
@@ -513,8 +514,10 @@ class ProtBertForMaskedLM(nn.Module):
     def _check_ids(self, ids, values=True):
         """Shape, type and device of an id matrix; with `values`, also that every id is a row of the embedding table
         (torch's embedding raises on such an id; the kernels here would read or add into a neighbouring table).
-        The value check reads two numbers back from the device; a tensor that passed is remembered by address,
-        shape and version, so a fill loop that hands the same buffer back every iteration pays once."""
+        The value check reads two numbers back from the device; the tensor OBJECT that passed is remembered (weak
+        reference + version counter), so a fill loop that hands the same tensor back every iteration pays once, while
+        a new batch that the allocator happens to place at the old address is checked again.  The fill kernels write
+        into such a tensor without moving its version counter; what they write are sampled vocabulary indices."""
         if ids.dim() != 2 or ids.dtype != torch.int64:
             raise TypeError("input_ids must be a [B,S] int64 tensor")
         if ids.device != self.device:
@@ -522,14 +525,15 @@ class ProtBertForMaskedLM(nn.Module):
         self._guard_device()
         if ids.shape[1] > self.config.max_position_embeddings:
             raise ValueError("sequence longer than max_position_embeddings")
+        given = ids
         ids = ids.contiguous()
         if values and ids.numel():
-            key = (ids.data_ptr(), tuple(ids.shape), ids._version)
-            if key != getattr(self, "_ids_checked", None):
+            seen = getattr(self, "_ids_checked", None)
+            if seen is None or seen[0]() is not given or seen[1] != given._version:
                 lo, hi = (int(v) for v in torch.aminmax(ids))
                 if lo < 0 or hi >= self.config.vocab_size:
                     raise IndexError(f"token id out of range: ids span [{lo}, {hi}], vocabulary has {self.config.vocab_size}")
-                self._ids_checked = key
+                self._ids_checked = (weakref.ref(given), given._version)
         return ids
 
     def _mask01(self, mask, B, S):

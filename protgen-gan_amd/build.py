@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libprotgen_hip.so")
-SOURCES = ["gemm.hip", "gemm_ring.hip", "gemm_persist.hip", "attention.hip", "rowwise.hip", "misc.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "misc.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", INCLUDE]
 
 

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int* kidx = nullptr;
   if (key_cnt) {
     const int c = key_cnt[b];
-    if (c >= 0) {
+    if (c > 0 && c <= S) {  // (anything else, -1 included: the whole walk under the additive mask)
       Sk = c;
       kidx = key_idx + row0;
     }

@@ -455,7 +455,6 @@ int launch_glds_pair(const pg_gemm_desc* d, const GemmArgs2& a, int blocks, hipS
 // fragment addressing are shared with the 128x128 kernel).  A wave keeps 128 accumulator
 // registers and walks a k-tile in four chunks (k-step x row half), each chunk's fragment reads
 // issued one chunk ahead of the MFMAs that consume them.
-int g_gemm_dbg = 0;
 
 
 __device__ __forceinline__ void mfma_4x4(f32x4 (&acc)[8][4], int i0, const u32x4 (&a)[4], const u32x4 (&b)[4]) {
@@ -590,10 +589,7 @@ int launch_glds256_group(const pg_gemm_desc* d, const GemmArgsG& a, int blocks, 
 template <typename TC>
 int launch_glds256(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
   dim3 grid((d->N + 255) / 256, (d->M + 255) / 256, d->batch);
-  if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 1) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 1>), grid, dim3(NT256), 0, st, a);
-  else if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 2) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 2>), grid, dim3(NT256), 0, st, a);
-  else if (d->a_kmajor && d->b_kmajor && g_gemm_dbg == 3) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true, 3>), grid, dim3(NT256), 0, st, a);
-  else if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true>), grid, dim3(NT256), 0, st, a);
+  if (d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, true>), grid, dim3(NT256), 0, st, a);
   else if (d->a_kmajor && !d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, true, false>), grid, dim3(NT256), 0, st, a);
   else if (!d->a_kmajor && d->b_kmajor) hipLaunchKernelGGL((gemm_glds256_kernel<TC, false, true>), grid, dim3(NT256), 0, st, a);
   else hipLaunchKernelGGL((gemm_glds256_kernel<TC, false, false>), grid, dim3(NT256), 0, st, a);
@@ -771,10 +767,9 @@ int launch_glds_n64(const pg_gemm_desc* d, const GemmArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-int g_gemm_ring = 0;  // 1 = the five-slot ring kernel (gemm_ring.hip) for k-major x k-major products on 256x256 tiles (pg_tune key 21)
-int g_gemm_persist = 0;  // 256-tile products (A k-major) with more tiles than workgroups run persistent workgroups that walk their tiles (gemm_persist.hip; pg_tune key 24): 1 = one per CU, n > 1 = n workgroups, 0 = off
+// Dispatch thresholds and switches.  Process-global, set through pg_tune by tests and A/B measurements only; the
+// values here are what every product run uses.  Not synchronised: pg_tune must not run beside a launch.
 int g_gemm_epi_prefetch = 1;  // bf16 epilogues fetch their per-element operand (pre-activation, residual or C) for the whole wave tile up front (pg_tune key 23)
-int g_gemm_nt_store_mb = 0;  // bf16 outputs of at least this many MiB leave with streaming stores (pg_tune key 22; 0 = never)
 int g_gemm_narrow = 1;  // 1 = 128x64 tiles when N <= 64, 2 = also whenever the 128x128 grid has <= 256 workgroups, 0 = never
 
 int g_gemm_wide = 1;  // 1 = 256x256 tiles for large-N products with enough tiles to cover the chip, 2 = always, 0 = never
@@ -783,7 +778,6 @@ int g_gemm_ep8 = 1;   // 16-byte epilogue accesses for bf16 outputs (0 = 8-byte 
 int g_gemm_pair = 1;  // 0 = pg_gemm_pair launches its two products one after the other
 int g_gemm_dualk = 1;  // 0 = a two-segment product runs as two launches
 int g_gemm_group_m = 8;  // tile rows per group of the grouped tile order (1 = plain row-major)
-int g_gemm_small_grid = 0;  // most 128x128 tiles of an unbatched product that takes 128x64 tiles instead (pg_tune key 19; off)
 int g_gemm_split_tail = 50;  // 256-tile products: the rows of a last round less than this many per cent full go to a second launch (0 = never)
 int g_gemm_wide_min_k = 1024;  // smallest K for which a narrow-N product with many tiles takes the 256-tile kernel
 int g_gemm_group = 1;  // 0 = pg_gemm_group launches its products in pairs / singly
@@ -796,9 +790,6 @@ int g_gemm_deep_max_blocks = 256;
 
 }  // namespace
 
-int pg_internal_launch_ring256(const void* args, int M, int N, int c_is_f32, hipStream_t st);
-int pg_internal_launch_persist256(const void* args, int M, int N, int b_kmajor, int c_is_f32, int workgroups, hipStream_t st);
-extern int pg_internal_ring_dbg;
 int pg_internal_fused_gp = 1;  // fused attention kernels in the gradient-penalty passes (engine)
 
 extern int pg_internal_colsum_chunks;
@@ -811,7 +802,6 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
   if (key == 2) { g_gemm_wide = value; return PG_OK; }
-  if (key == 3) { g_gemm_dbg = value; return PG_OK; }
   if (key == 4) { g_gemm_ep8 = value; return PG_OK; }
   if (key == 5) { g_gemm_pair = value; return PG_OK; }
   if (key == 6) { pg_internal_fused_gp = value; return PG_OK; }
@@ -827,12 +817,8 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 17) { if (value != 4 && value != 16) return PG_ERR_ARG; pg_internal_colsum_waves = value; return PG_OK; }
   if (key == 10) { g_gemm_wide_min_k = value; return PG_OK; }
   if (key == 9) { if (value < 0 || value > 100) return PG_ERR_ARG; g_gemm_split_tail = value == 1 ? 50 : value; return PG_OK; }
-  if (key == 19) { if (value < 0) return PG_ERR_ARG; g_gemm_small_grid = value; return PG_OK; }
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
-  if (key == 24) { if (value < 0) return PG_ERR_ARG; g_gemm_persist = value; return PG_OK; }
   if (key == 23) { g_gemm_epi_prefetch = value ? 1 : 0; return PG_OK; }
-  if (key == 22) { if (value < 0) return PG_ERR_ARG; g_gemm_nt_store_mb = value; return PG_OK; }
-  if (key == 21) { g_gemm_ring = value ? 1 : 0; pg_internal_ring_dbg = value == 2; return PG_OK; }
   return PG_ERR_ARG;
 }
 
@@ -874,8 +860,7 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   // the 256 rows a sparse last round of 256x256 tiles leaves over take 14 us that way against 25-30 us at K = 1024;
   // inside the GAN step the four-buffer 128x128 kernel is the faster one, 846 against 850-854 ms per step: off)
   const bool narrow = fast && ((g_gemm_narrow >= 1 && d->N <= 64) || (d->K2 == 0 && g_gemm_narrow == 2 && blocks128 <= 256) ||
-                              (d->K2 == 0 && g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024) ||
-                              (d->K2 == 0 && g_gemm_narrow == 1 && d->batch == 1 && !d->seq_off && blocks128 <= g_gemm_small_grid));
+                              (d->K2 == 0 && g_gemm_narrow == 3 && blocks128 <= 128 && d->K >= 1024));
   const bool wide = fast && !narrow &&
                     (g_gemm_wide == 2 || (g_gemm_wide >= 1 && d->N >= 2048 && tiles256(d) >= 160) ||
                      // narrow N but long K: the halved L2 -> LDS traffic outweighs a partial round as soon as the
@@ -923,11 +908,6 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
   if (narrow) {
     if (d->c_dtype == PG_F32) rc = launch_glds_n64<float>(d, a, st);
     else rc = launch_glds_n64<bf16_t>(d, a, st);
-  } else if (wide && g_gemm_ring && d->a_kmajor && d->b_kmajor && d->batch == 1 && d->K + d->K2 >= 2 * GBK) {
-    rc = pg_internal_launch_ring256(&a, d->M, d->N, d->c_dtype == PG_F32, st);
-  } else if (wide && g_gemm_persist && d->a_kmajor && d->batch == 1 && g_gemm_dbg == 0 &&
-             tiles256(d) > (g_gemm_persist == 1 ? device_cus() : g_gemm_persist)) {
-    rc = pg_internal_launch_persist256(&a, d->M, d->N, d->b_kmajor, d->c_dtype == PG_F32, g_gemm_persist == 1 ? device_cus() : g_gemm_persist, st);
   } else if (wide) {
     if (d->c_dtype == PG_F32) rc = launch_glds256<float>(d, a, st);
     else rc = launch_glds256<bf16_t>(d, a, st);
@@ -998,6 +978,9 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
     // score-shaped operand are walked (zeros past the extent), token-row operands are clamped
     if (d->dtype != PG_BF16 || d->N > 64 || d->N % 8 || d->M != d->K || d->seq_tok0 < 0 || (d->seq_ops & ~7)) return PG_ERR_UNSUPPORTED;
     if (d->b_kmajor || d->bias || d->residual || d->aux) return PG_ERR_UNSUPPORTED;
+    // A must be the score-shaped operand: its reduction rows past a sequence's extent are zeros by the layout's
+    // contract, which is what ends the sum; a token-row A would run on into the next sequence's rows
+    if (d->seq_ops & 1) return PG_ERR_UNSUPPORTED;
   }
   if (d->K2 > 0) {
     if (!d->A2 || !d->B2 || (d->batch != 1 && d->N > 64)) return PG_ERR_ARG;
@@ -1022,7 +1005,7 @@ int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a) {
     if (d->aux) v8 = v8 && (d->ldaux % 8 == 0) && (((uintptr_t)d->aux) % 16 == 0);
     if (a.aux2) v8 = v8 && (((uintptr_t)a.aux2) % 16 == 0);
     if (v8 && g_gemm_ep8) {
-      a.vec_ok = (g_gemm_nt_store_mb > 0 && (double)d->M * d->N * 2 >= g_gemm_nt_store_mb * 1048576.0 && d->beta == 0.f) ? 3 : 2;
+      a.vec_ok = 2;
     }
   }
   if (a.vec_ok && g_gemm_epi_prefetch) a.vec_ok |= 4;  // (vec_ok: bits 0-1 = access width class, bit 2 = operand prefetch)

@@ -198,7 +198,6 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
   const int gq = lane >> 4;
   const int m0 = m_base + (lane & 15);
   const int m_last = g.M - 1;  // (rows past it: computed, never stored, their operands read from row m_last)
-  const bool nt = (g.vec_ok & 3) == 3;  // streaming stores of the output (pg_tune key 22)
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
   const bf16_t* res = reinterpret_cast<const bf16_t*>(g.residual);
   // this lane's two column groups (jh = 0, 2) and their biases
@@ -289,10 +288,7 @@ __device__ __forceinline__ void gemm_epilogue_interior_b8(f32x4 (&acc)[MI][4], c
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += g.beta * c0[e];
       }
-      if (row_ok) {
-        if (nt) VecIO<bf16_t, 8>::store_nt(Cp + m * g.ldc + nn[h], v);
-        else VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
-      }
+      if (row_ok) VecIO<bf16_t, 8>::store(Cp + m * g.ldc + nn[h], v);
     }
   }
 }

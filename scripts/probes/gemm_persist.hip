@@ -1,3 +1,6 @@
+// PROBE, not part of libprotgen_hip.so: measured against the shipped 256x256 kernel and not faster (results under
+// profiles/r02_d_ring_ab*.txt, profiles/r02_f_persist_ab*.txt).  To rebuild the experiment, add this file to SOURCES in
+// protgen-gan_amd/build.py and route pg_gemm's wide branch to its pg_internal_launch_* entry point.
 // Persistent form of the 256 x 256-tile direct-to-LDS GEMM (bf16 operands, A k-major, unbatched).
 // Off by default (pg_tune key 24): measured slower than one workgroup per tile, see below.
 //

@@ -1,3 +1,6 @@
+// PROBE, not part of libprotgen_hip.so: measured against the shipped 256x256 kernel and not faster (results under
+// profiles/r02_d_ring_ab*.txt, profiles/r02_f_persist_ab*.txt).  To rebuild the experiment, add this file to SOURCES in
+// protgen-gan_amd/build.py and route pg_gemm's wide branch to its pg_internal_launch_* entry point.
 // 256 x 256-tile bf16 GEMM over a five-slot LDS ring (k-major x k-major operands); a translation unit of
 // its own so that it builds in seconds.  pg_gemm (gemm.hip) decides which products take it.
 #include "pg_common.h"

@@ -26,7 +26,6 @@ def pg():
 
 DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
-PERSIST_DEFAULT = 0  # the library's initial pg_tune key 24
 
 
 def tol(dtype):
@@ -80,16 +79,11 @@ def test_gemm_exact_layouts(pg, dtype, ak, bk, kfull, narrow):
     assert torch.equal(out.cpu().double(), ref)
 
 
-@pytest.fixture(params=[(1, 0), (0, 0), (0, 8), (0, 3)], ids=["ring", "two_stage", "persistent8", "persistent3"])
+@pytest.fixture(params=[(0, 0)], ids=["two_stage"])
 def ring(request, pg):
-    """Every 256x256-tile kernel: the two-stage one, the five-slot ring (k-major x k-major products) and the
-    persistent form (A k-major), here with 8 and with 3 workgroups so that the few tiles of a test shape are
-    more than one per workgroup (unevenly: some walk two or three tiles, some one)."""
-    pg._lib.lib.pg_tune(21, request.param[0])
-    pg._lib.lib.pg_tune(24, request.param[1])
+    """The 256x256-tile kernel the library ships: two 64 KiB stages, one workgroup per tile.  (A five-slot ring and a
+    persistent form were measured against it and lost; their sources are kept under scripts/probes/.)"""
     yield request.param
-    pg._lib.lib.pg_tune(21, 0)
-    pg._lib.lib.pg_tune(24, PERSIST_DEFAULT)
 
 
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
@@ -327,7 +321,7 @@ def test_gemm_split_last_round_two_segments(pg, ring):
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("shape", [(256, 1024, 4096), (200, 392, 1024), (128, 128, 2048), (640, 1024, 1536)])
 def test_gemm_small_grid_exact(pg, ak, bk, shape):
-    """With pg_tune key 19, products of at most that many tiles of 128x128 take the 128x64-tile kernel: small-integer
+    """With pg_tune key 1 = 2, products of at most 256 tiles of 128x128 take the 128x64-tile kernel: small-integer
     operands, exact against fp64, ragged M and N edges, every layout; equal to the 128x128 kernel's result."""
     from protgen_gan_amd._lib import lib
     g = torch.Generator().manual_seed(77)
@@ -343,11 +337,11 @@ def test_gemm_small_grid_exact(pg, ak, bk, shape):
     bf = torch.bfloat16
     Ad = (A if ak else A.T.contiguous()).to(bf).to(DEV)
     Bd = (B if bk else B.T.contiguous()).to(bf).to(DEV)
-    lib.pg_tune(19, 64)
+    lib.pg_tune(1, 2)
     try:
         out = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
     finally:
-        lib.pg_tune(19, 0)
+        lib.pg_tune(1, 1)
     assert torch.equal(out.cpu().double(), ref)
     plain = pg.ops.gemm(Ad, Bd, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
     assert torch.equal(plain, out)
@@ -375,11 +369,11 @@ def test_gemm_small_grid_epilogues(pg):
         torch.cuda.synchronize()
         return [o1, aux, o2, o3, gu]
 
-    lib.pg_tune(19, 64)
+    lib.pg_tune(1, 2)
     try:
         small = run()
     finally:
-        lib.pg_tune(19, 0)
+        lib.pg_tune(1, 1)
     plain = run()
     for a, c in zip(small, plain):
         assert torch.equal(a, c)
