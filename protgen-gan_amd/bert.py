@@ -85,6 +85,28 @@ def workspace(device, nbytes: int) -> torch.Tensor:
     return w
 
 
+_STASH_POOLS: Dict[tuple, torch.Tensor] = {}
+
+
+def pooled_stash(device, role: str, nbytes: int, reserve: int = 0) -> torch.Tensor:
+    """`nbytes` of a grow-only buffer kept per (device, role), for the stashes of the hand-scheduled update passes
+    (roles: the primal stash of a forward, the adjoint stash of a first-order backward, the tangent stash).  Their
+    sizes follow the packed token count, which differs from one update to the next; taken from the caching allocator
+    they leave a trail of multi-gigabyte blocks none of which fits the next request, until the allocator gives
+    everything back to the driver in the middle of a step (seconds).  `reserve`: the size to allocate when the buffer
+    has to grow (the largest the caller will ever ask for).  All users are ordered on the current stream; a buffer
+    handed out under a role is dead by the time the role is asked for again."""
+    key = (device, role)
+    w = _STASH_POOLS.get(key)
+    if w is None or w.numel() < nbytes:
+        if w is not None:
+            torch.cuda.synchronize(device)
+            del _STASH_POOLS[key], w
+        w = torch.empty(max(int(nbytes), int(reserve)) + 4096, dtype=torch.uint8, device=device)
+        _STASH_POOLS[key] = w
+    return w[:nbytes]
+
+
 # ----------------------------------------------------------------------------- flat parameter store
 class FlatStore:
     """fp32 master parameters in one buffer (+ bf16 shadow, + flat gradient buffer)."""
@@ -589,11 +611,19 @@ class ProtBertForMaskedLM(nn.Module):
             raise ValueError("unsupported shape")
         return workspace(self.device, n), n
 
-    def _new_stash(self, B, S, T=None):
+    def _new_stash(self, B, S, T=None, role=None):
+        """Stash bytes for a pass over B x S (or T ragged token rows).  `role`: take them from the per-role pool
+        (pooled_stash) instead of the allocator; only for callers that are done with the stash before they ask for
+        the role again."""
         dt = ops.dt_code(self.compute_dtype)
         n = (lib.pg_stash_bytes(C.byref(self._ccfg), dt, B, S) if T is None
              else lib.pg_stash_bytes_ragged(C.byref(self._ccfg), dt, B, S, T))
-        return torch.empty(n, dtype=torch.uint8, device=self.device)
+        if role is None:
+            return torch.empty(n, dtype=torch.uint8, device=self.device)
+        # (packed token counts wander by a few per cent from update to update: a fifth of headroom, at most the
+        # rectangle's size, lets the pool settle after the first few updates)
+        most = n if T is None else min(lib.pg_stash_bytes_ragged(C.byref(self._ccfg), dt, B, S, B * S), n + n // 5)
+        return pooled_stash(self.device, role, n, reserve=most)
 
     # -- ragged passes (rows of different lengths laid back to back; see ragged.py)
     def _embed_packed(self, ids_p, pos_p, out, esum):
@@ -619,12 +649,12 @@ class ProtBertForMaskedLM(nn.Module):
                                           self._gg(_lib.P_POS_EMB), self._gg(_lib.P_TYPE_EMB), T, H, ops.stream()),
               "pg_embed_scatter_packed")
 
-    def _encode_ragged(self, rg, ids_p=None, pos_p=None, x=None, mask_p=None, want_stash=False, esum=None):
+    def _encode_ragged(self, rg, ids_p=None, pos_p=None, x=None, mask_p=None, want_stash=False, esum=None, stash_role=None):
         """Forward over the ragged batch `rg` (a ragged.Ragged): packed ids + positions, or x [T,H]; mask_p fp32 [T]
-        or None.  Returns (hidden [T,H], stash or None)."""
+        or None.  Returns (hidden [T,H], stash or None).  `stash_role`: see _new_stash."""
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(rg.B, rg.S, rg.T)
-        stash = self._new_stash(rg.B, rg.S, rg.T) if want_stash else None
+        stash = self._new_stash(rg.B, rg.S, rg.T, role=stash_role) if want_stash else None
         hidden = torch.empty(rg.T, self.config.hidden_size, dtype=self.compute_dtype, device=self.device)
         pr = _params_struct(self.store, self.compute_dtype, False)
         d = rg.desc()
@@ -633,12 +663,12 @@ class ProtBertForMaskedLM(nn.Module):
                                             ops.ptr(esum), ops.stream()), "pg_encoder_forward_ragged")
         return hidden, stash
 
-    def _encode(self, ids, x, mask, want_stash=False, esum=None):
+    def _encode(self, ids, x, mask, want_stash=False, esum=None, stash_role=None):
         """Embeddings (if ids) + all encoder layers.  Returns (hidden [B,S,H], stash or None)."""
         B, S = (ids.shape if ids is not None else x.shape[:2])
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(B, S)
-        stash = self._new_stash(B, S) if want_stash else None
+        stash = self._new_stash(B, S, role=stash_role) if want_stash else None
         hidden = torch.empty(B, S, self.config.hidden_size, dtype=self.compute_dtype, device=self.device)
         pr = _params_struct(self.store, self.compute_dtype, False)
         check(lib.pg_encoder_forward(C.byref(self._ccfg), C.byref(pr), dt, B, S, ops.ptr(ids), ops.ptr(x), ops.ptr(mask),

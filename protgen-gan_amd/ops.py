@@ -62,9 +62,9 @@ def gemm_pair(A0, B0, C0, A1, B1, C1, *, a_kmajor=True, b_kmajor=True, alpha=1.0
 
 
 def gemm_group(problems, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0):
-    """Up to four 2-D GEMMs of one layout in one launch (pg_gemm_group).  `problems` is a list of
+    """Up to sixteen 2-D GEMMs of one layout in one launch (pg_gemm_group).  `problems` is a list of
     (A, B, C) or (A, B, C, A2, B2) tuples; outputs must be given."""
-    assert 1 <= len(problems) <= 4
+    assert 1 <= len(problems) <= 16
     arr = (_lib.GemmDesc * len(problems))()
     for i, pr in enumerate(problems):
         A, B, Cm = pr[:3]

@@ -306,7 +306,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     m._embed(fake, X[2 * B:], sum_f)
     check(lib.pg_interpolate(dt, X[B:2 * B].data_ptr(), X[2 * B:].data_ptr(), alpha.data_ptr(), X[:B].data_ptr(), B, S * H, st),
           "pg_interpolate")
-    hidden, stash = m._encode(None, X, mask3, want_stash=True)
+    hidden, stash = m._encode(None, X, mask3, want_stash=True, stash_role="primal")
     del X
     scores = torch.empty(3 * B, 1, dtype=torch.float32, device=dev)
     hstash = torch.empty(3 * B, lib.pg_head_stash_floats(H), dtype=torch.float32, device=dev)
@@ -331,7 +331,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
                                    st), "pg_head_backward")
         check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
                                    ghead.data_ptr(), dh3[B:].data_ptr(), S * H, st), "pg_head_backward")
-        adj = m._new_stash(3 * B, S)
+        adj = m._new_stash(3 * B, S, role="adjoint")
         adj_rows = 3 * B
         dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B)
         g = dx3[:B]
@@ -341,7 +341,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
         dh = torch.zeros(B, S, H, dtype=cd, device=dev)
         check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dh.data_ptr(), S * H,
                                    st), "pg_head_backward")
-        adj = m._new_stash(B, S)
+        adj = m._new_stash(B, S, role="adjoint")
         adj_rows = 0
         g = m._encode_backward(stash, dh, B, S, param_grads=False, adj_stash=adj, stash_rows=3 * B, row0=0)
         dh2 = torch.zeros(2 * B, S, H, dtype=cd, device=dev)
@@ -357,7 +357,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     v = torch.empty_like(g)
     check(lib.pg_gp_direction(dt, g.data_ptr(), joint.data_ptr(), norms.data_ptr(), B, S, H, scale.data_ptr(), v.data_ptr(),
                               None, st), "pg_gp_direction")
-    tan = m._new_stash(B, S)
+    tan = m._new_stash(B, S, role="tangent")
     hdot = m._encode_jvp(stash, v, B, S, tan, stash_rows=3 * B, row0=0)
     tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
     check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot.data_ptr(), S * H, B, H, 1.0,
@@ -412,7 +412,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     check(lib.pg_interpolate_ragged(dt, X[Tj:].data_ptr(), X[Tj:].data_ptr(), alpha.data_ptr(), X.data_ptr(),
                                     rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H, st),
           "pg_interpolate_ragged")
-    hidden, stash = m._encode_ragged(rg3, x=X, mask_p=mask3, want_stash=True)
+    hidden, stash = m._encode_ragged(rg3, x=X, mask_p=mask3, want_stash=True, stash_role="primal")
     del X
     cls = hidden.index_select(0, rg3.cls_rows)  # [3B, H]: the rows the critic reads (models.py:104)
     scores = torch.empty(3 * B, 1, dtype=torch.float32, device=dev)
@@ -437,7 +437,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
         check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
                                    ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
         dh3 = torch.zeros(T3, H, dtype=cd, device=dev).index_copy_(0, rg3.cls_rows, dcls)
-        adj = m._new_stash(3 * B, S, T3)
+        adj = m._new_stash(3 * B, S, T3, role="adjoint")
         dx3 = m._encode_backward(stash, dh3, 3 * B, S, param_grads=True, adj_stash=adj, grad_row0=B, rgd=rg3.desc(), T=T3)
         g, dx2 = dx3[:Tj], dx3[Tj:]
     else:
@@ -454,7 +454,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     v = torch.empty_like(g)
     check(lib.pg_gp_direction_ragged(dt, g.data_ptr(), mask3.data_ptr(), norms.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H,
                                      scale.data_ptr(), v.data_ptr(), None, st), "pg_gp_direction_ragged")
-    tan = m._new_stash(B, S, Tj)
+    tan = m._new_stash(B, S, Tj, role="tangent")
     hdot = m._encode_jvp(stash, v, B, S, tan, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
     hdot_cls = hdot.index_select(0, rgJ.cls_rows)
     tstash = torch.empty(B, hstash.shape[1], dtype=torch.float32, device=dev)
@@ -559,7 +559,7 @@ def _generator_scores_ragged(critic: Critic, fake, fake_mask, lens) -> torch.Ten
     X = torch.empty(T, H, dtype=cd, device=dev)
     sums = torch.empty(T, H, dtype=cd, device=dev) if train_encoder else None
     m._embed_packed(ids_p, rg.pos, X, sums)
-    hidden, stash = m._encode_ragged(rg, x=X, mask_p=mask_p, want_stash=train_encoder)
+    hidden, stash = m._encode_ragged(rg, x=X, mask_p=mask_p, want_stash=train_encoder, stash_role="primal")
     del X
     cls = hidden.index_select(0, rg.cls_rows)
     scores = torch.empty(B, 1, dtype=torch.float32, device=dev)
