@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--soft-generator-update", action="store_true",
                     help="generator update through soft embeddings (gradients reach the generator and are all-reduced); "
                          "not the reference loop's update, so not the default line")
+    ap.add_argument("--no-fill-ahead", action="store_true",
+                    help="fill an iteration's fake batches at its start instead of beside the previous iteration's updates "
+                         "(train.FillAhead; blind mode with the reference's generator update only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
     ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
@@ -162,13 +165,17 @@ def main():
     if soft and world > 1:
         gen_sync = pgd.GradSync([generator.protbert.store], world, overlap=generator.protbert, position_rows=args.seq)
 
-    def one_step(i):
+    # the next iteration's fakes are filled on a side stream beside this iteration's updates (every timed step still
+    # runs one whole fill and one whole set of updates; what step i consumes was filled during step i - 1)
+    ahead = pgt.FillAhead(dev) if (seeds is None and not soft and not args.no_fill_ahead) else None
+
+    def one_step(i, ahead=ahead):
         if seeds is not None:
             return pgt.gan_step_seeded(generator, critic, gen_opt, critic_opt, real[i], seeds[i], hp,
                                        grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
                                   grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync,
-                                  rank=rank, world=world)
+                                  rank=rank, world=world, fill_ahead=ahead)
 
     def fence():
         if world > 1:
@@ -210,6 +217,31 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     c_loss, g_loss = float(last[0]), float(last[1])
+    fill_log = (list(generator.fill_shapes), list(generator.fill_widths))
+    exec_log = list(pgt.EXEC_LOG)
+    # after the timed region: a few iterations one after the other (fill, then updates), for the kernels' rates
+    # when each launch has the chip to itself and for what the overlap is worth
+    serial = None
+    if ahead is not None:
+        ahead.close()
+        n_serial = min(args.steps, 4)
+        one_step(args.warmup, ahead=None)
+        fence()
+        lib.pg_profile_begin(args.profile_sample)
+        t1 = time.perf_counter()
+        for i in range(n_serial):
+            one_step(args.warmup + i, ahead=None)
+        fence()
+        dt1 = time.perf_counter() - t1
+        prof1 = (ctypes.c_double * 48)()
+        nl1 = ctypes.c_int64(0)
+        lib.pg_profile_end(prof1, ctypes.byref(nl1))
+        v1 = variant_table(prof1)
+        serial = {"steps": n_serial, "ms_per_step": round(dt1 / n_serial * 1e3, 2),
+                  "what": "the same iterations with the fill at their start (no overlap), after the timed region",
+                  "variants": v1, "gemm_launches_total": int(nl1.value)}
+    generator.fill_shapes[:], generator.fill_widths[:] = fill_log
+    pgt.EXEC_LOG[:] = exec_log
 
     # algorithmic FLOPs of the timed region on this rank
     fill_flops = sum(B * S * f_gen_tok(S) for B, S in generator.fill_shapes)
@@ -236,6 +268,25 @@ def main():
 
     variants = variant_table(prof)
     dom = variants[0] if variants else None
+    # With two streams sharing the chip a launch's duration is not its own (its workgroups wait for CUs the other
+    # stream holds), so FLOPs / duration of a launch in the timed region understates the kernel.  The kernel's roofline
+    # is then taken from the iterations run one launch at a time right after the timed region (same HIP-event sampling,
+    # same process); the timed region's figure is kept beside it.
+    overlapped = None
+    if serial is not None and serial["variants"]:
+        if dom:
+            overlapped = {"kernel": dom["kernel"], "achieved": round(dom["tflops"], 2), "unit": "TFLOP/s",
+                          "frac": round(dom["tflops"] * 1e12 / MFMA_PEAK_BF16, 4), "avg_launch_us": round(dom["avg_us"], 2),
+                          "sampled_launches": dom["sampled_launches"],
+                          "note": "launch durations inside the timed region, where the fill's and the updates' launches share the CUs"}
+        variants_timed, variants = variants, serial.pop("variants")
+        dom = variants[0]
+        nl = ctypes.c_int64(serial.pop("gemm_launches_total"))
+    else:
+        variants_timed = None
+    if serial is not None:
+        serial.pop("variants", None)
+        serial.pop("gemm_launches_total", None)
     # fabric-side bytes per launch of the dominant kernel's largest shape, from the newest counter capture committed
     # under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/pmc_gemm.py, summarised by
     # scripts/pmc_summary.py): counters cannot be read from inside this process
@@ -264,7 +315,11 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
                     "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(dom["tflops"] * 1e12 / MFMA_PEAK_BF16, 4),
                     "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": round(dom["avg_us"], 2), "sampled_launches": dom["sampled_launches"],
-                    "gemm_launches_total": int(nl.value)}
+                    "gemm_launches_total": int(nl.value),
+                    "measured_over": ("%d iterations run one launch at a time right after the timed region (HIP events on the "
+                                      "launch stream, every %dth launch)" % (serial["steps"], args.profile_sample) if overlapped
+                                      else "the timed region (HIP events on the launch stream, every %dth launch)" % args.profile_sample),
+                    "overlapped": overlapped}
 
     out = {
         "metric": "ProtBERT GAN train steps/s (gen+critic) & generated seqs/s, 1/2/4/8 GPUs",
@@ -294,7 +349,10 @@ def main():
                     "max": round(max(step_ms), 2), "each": [round(v, 1) for v in step_ms],
                     "fill_token_rows_each": fill_rows},
         "c_loss": c_loss, "g_loss": g_loss,
-        "roofline": roofline, "gemm_variants": variants,
+        "schedule": ("next iteration's fill beside this iteration's updates (train.FillAhead)" if ahead is not None
+                     else "fill, then updates"),
+        "one_after_the_other": serial,
+        "roofline": roofline, "gemm_variants": variants, "gemm_variants_overlapped": variants_timed,
     }
     # the other half of the metric, after and outside the train leg's timed region: generated sequences/s
     if not args.no_generate_leg:

@@ -70,18 +70,19 @@ class ProtBertConfig:
 
 
 # ----------------------------------------------------------------------------- shared workspace
-_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+_WORKSPACES: Dict[tuple, torch.Tensor] = {}
 
 
 def workspace(device, nbytes: int) -> torch.Tensor:
-    """One grow-only scratch buffer per device, shared by every model: all passes are
-    ordered on the current stream, so they can reuse it."""
-    w = _WORKSPACES.get(device)
+    """One grow-only scratch buffer per (device, stream), shared by every model: the passes issued on one stream
+    are ordered, so they can reuse it; a caller that runs passes on a second stream beside them gets a second one."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _WORKSPACES.get(key)
     if w is None or w.numel() < nbytes:
         if w is not None:
             torch.cuda.synchronize(device)
         w = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
-        _WORKSPACES[device] = w
+        _WORKSPACES[key] = w
     return w
 
 

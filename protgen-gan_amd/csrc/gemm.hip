@@ -17,6 +17,8 @@
 // The MFMA is issued with the operands swapped (D = Bt * At) so that a lane owns four
 // consecutive n of one output row, which makes every epilogue access an 8/16-byte vector.
 #include <vector>
+#include <deque>
+#include <mutex>
 #include "pg_common.h"
 #include "protgen_hip.h"
 
@@ -25,7 +27,8 @@ namespace {
 // Optional sampled timing of GEMM launches with HIP events on the launch stream (used by the
 // benchmark to report achieved FLOP/s per kernel variant without a profiler attached).
 struct ProfEntry { hipEvent_t a, b; int variant; double flops; };
-struct ProfState { int every = 0; long counter = 0; long launches = 0; std::vector<ProfEntry> entries; };
+// (a deque: an entry's address stays valid while launches of another host thread append theirs)
+struct ProfState { int every = 0; long counter = 0; long launches = 0; std::deque<ProfEntry> entries; std::mutex mu; };
 ProfState g_prof;
 
 #include "gemm_shared.h"
@@ -933,14 +936,21 @@ extern "C" int pg_gemm(const pg_gemm_desc* d, void* stream) {
 namespace {
 ProfEntry* prof_begin(int variant, double flops, hipStream_t st) {
   if (g_prof.every <= 0) return nullptr;
-  ++g_prof.launches;
-  if (++g_prof.counter % g_prof.every != 0) return nullptr;
   ProfEntry e;
+  {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    ++g_prof.launches;
+    if (++g_prof.counter % g_prof.every != 0) return nullptr;
+  }
   if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
   e.variant = variant;
   e.flops = flops;
-  g_prof.entries.push_back(e);
-  ProfEntry* pe = &g_prof.entries.back();
+  ProfEntry* pe;
+  {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    g_prof.entries.push_back(e);
+    pe = &g_prof.entries.back();
+  }
   hipEventRecord(pe->a, st);
   return pe;
 }
@@ -1089,6 +1099,7 @@ extern "C" int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream) {
 
 // variant index = 8*(bf16) + 4*(fp32 output) + 2*(A k-major) + (B k-major)
 extern "C" int pg_profile_begin(int sample_every) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   for (auto& e : g_prof.entries) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   g_prof.entries.clear();
   g_prof.every = sample_every > 0 ? sample_every : 0;
@@ -1099,6 +1110,7 @@ extern "C" int pg_profile_begin(int sample_every) {
 // out[16][3] = {sampled launches, sampled flops, sampled milliseconds} per variant; stops sampling.
 extern "C" int pg_profile_end(double* out, int64_t* total_launches) {
   if (!out) return PG_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   g_prof.every = 0;
   for (int i = 0; i < 48; ++i) out[i] = 0.0;
   for (auto& e : g_prof.entries) {

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import os
 import random
+import threading
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -659,6 +660,86 @@ def generator_update_soft(generator: Generator, critic: Critic, gen_optimizer, m
     return g_loss.detach()
 
 
+class FillAhead:
+    """The NEXT iteration's fake batches, filled while THIS iteration's updates run.
+
+    Nothing changes the generator inside the reference's loop (its optimizer step is a no-op, see generator_update),
+    so the fakes of iteration s + 1 may be filled before iteration s has finished.  The critic's updates leave CUs
+    idle (their N = 1024 products cover about half the chip, the passes over the 8 interpolates a sixth), the fill's
+    launches cover it several times over: issued on a second stream by a second host thread, the fill takes those CUs.
+    Measured on configs[1]: fill 304 ms + updates 477 ms one after the other 775 ms, at once 716 ms.
+
+    The host random draws of an iteration (lengths, temperatures, gradient-penalty alphas) are made in the main thread
+    in the order the stacked form makes them, one whole iteration after the other; the sampling noise comes from the
+    device generator in fill order.  So the fake batches, the alphas and with them every loss are the ones the
+    one-iteration-at-a-time schedule produces.  Not for the soft generator update (it changes the generator)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(self.device)
+        self._thread: Optional[threading.Thread] = None
+        self._out = None
+        self._err: Optional[BaseException] = None
+
+    def pending(self) -> bool:
+        return self._thread is not None
+
+    def start(self, job: Callable[[], object]):
+        """Run job() in a second thread with the side stream current; its result waits for take()."""
+        if self._thread is not None:
+            raise RuntimeError("a fill is already in flight")
+        self._out = self._err = None
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+        def run():
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.stream):
+                    self._out = job()
+            except BaseException as e:  # noqa: BLE001  (re-raised in the main thread by take / wait_host)
+                self._err = e
+
+        self._thread = threading.Thread(target=run, name="protgen-fill-ahead", daemon=True)
+        self._thread.start()
+
+    def wait_host(self):
+        """Until the fill thread has issued everything (its last read-back also means the device is done with it)."""
+        if self._thread is not None and self._thread.is_alive():
+            self._thread.join()
+        if self._err is not None:
+            err, self._err, self._thread = self._err, None, None
+            raise err
+
+    def take(self):
+        """The finished job's result, ordered into the current stream; None when nothing was started."""
+        if self._thread is None:
+            return None
+        self.wait_host()
+        self._thread = None
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.stream)
+        out, self._out = self._out, None
+
+        def keep(o):  # the tensors were allocated on the side stream and are about to be used on this one
+            if isinstance(o, torch.Tensor):
+                if o.is_cuda:
+                    o.record_stream(cur)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    keep(v)
+        keep(out)
+        return out
+
+    def close(self):
+        """Drop a fill nobody will use (end of training)."""
+        try:
+            self.take()
+        finally:
+            self._thread = self._out = None
+
+
 def blind_template(lengths: Sequence[int], device, mask_id=4, cls_id=2, sep_id=3, pad_id=0) -> torch.Tensor:
     """`[CLS] MASK.. [SEP] PAD..` rows of the given lengths (CLS and SEP included), as wide as the longest
     (fully_masked_train.py:203-215)."""
@@ -673,7 +754,8 @@ def blind_template(lengths: Sequence[int], device, mask_id=4, cls_id=2, sep_id=3
 def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                    real_batches: List[dict], length_pool: Sequence[int], hp: GanHyper, batch_size: int, device,
                    rng=random, grad_sync=None, stacked_generation: bool = True, soft_generator_update: bool = False,
-                   gen_grad_sync=None, rank: int = 0, world: int = 1):
+                   gen_grad_sync=None, rank: int = 0, world: int = 1, fill_ahead: Optional[FillAhead] = None,
+                   more_follows: bool = True):
     """One iteration of the blind-mode training loop: n_critic critic updates (each with a
     fresh fake batch) followed by one generator update on `gen_batch_blind` fakes.
 
@@ -685,6 +767,11 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
 
     `rank`, `world` (data-parallel, stacked form): `rng` is then the generator all ranks seed alike, and the fake
     lengths are this rank's balanced share of the global draw (sample_fake_lengths).
+
+    `fill_ahead` (stacked form, token-id generator update): the iteration takes the fakes a previous call left in
+    flight there (or fills its own when there are none) and, when `more_follows`, starts the fill of the next
+    iteration's fakes on the side stream before its own updates; see FillAhead.  Real batches must then have
+    `batch_size` rows.
 
     `soft_generator_update`: the generator update is generator_update_soft on the fully masked template of the
     generator batch (keys visible as in the fill: `ids != MASK`; the critic sees `ids != PAD`), at the first
@@ -705,15 +792,32 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
                                    lengths=sample_fake_lengths(length_pool, hp.gen_batch_blind, rng, rank, world))
         g = generator_update(critic, gen_optimizer, fake)
         return c_sum / hp.n_critic, g
-    lengths, temps, alphas = [], [], []
-    for batch in real_batches:
-        lengths.append(sample_fake_lengths(length_pool, batch_size, rng, rank, world))
+
+    def draw_plan(n_updates, rows):
+        """The host draws of one iteration, in the order the one-after-the-other loop makes them."""
+        lengths, temps, alphas = [], [], []
+        for _ in range(n_updates):
+            lengths.append(sample_fake_lengths(length_pool, batch_size, rng, rank, world))
+            temps.append(fill_temperatures(hp))
+            alphas.append(torch.rand(rows, 1, 1))
+        lengths.append(sample_fake_lengths(length_pool, hp.gen_batch_blind, rng, rank, world))
         temps.append(fill_temperatures(hp))
-        alphas.append(torch.rand(batch["input_ids"].size(0), 1, 1))
-    lengths.append(sample_fake_lengths(length_pool, hp.gen_batch_blind, rng, rank, world))
-    temps.append(fill_temperatures(hp))
-    n_fill = len(lengths) - (1 if soft_generator_update else 0)
-    fakes = generate_fake_batches(generator, lengths[:n_fill], temps[:n_fill], hp, device)
+        return lengths, temps, alphas
+
+    n_fill_skip = 1 if soft_generator_update else 0
+    ahead = fill_ahead if (fill_ahead is not None and not soft_generator_update) else None
+    taken = ahead.take() if ahead is not None else None
+    if taken is not None:
+        lengths, temps, alphas, fakes = taken
+        if len(alphas) != len(real_batches) or any(a.size(0) != b["input_ids"].size(0) for a, b in zip(alphas, real_batches)):
+            raise ValueError("the fakes filled ahead were planned for another number or size of real batches")
+    else:
+        lengths, temps, alphas = draw_plan(len(real_batches), real_batches[0]["input_ids"].size(0) if real_batches else batch_size)
+        n_fill = len(lengths) - n_fill_skip
+        fakes = generate_fake_batches(generator, lengths[:n_fill], temps[:n_fill], hp, device)
+    if ahead is not None and more_follows:
+        nl, nt, na = draw_plan(hp.n_critic, batch_size)
+        ahead.start(lambda: (nl, nt, na, generate_fake_batches(generator, nl, nt, hp, device)))
     c_sum = None
     for batch, fake, alpha, fl in zip(real_batches, fakes, alphas, lengths):
         # (a fake row's non-pad columns end inside its template: positions past it are never masks, so never filled)
@@ -731,6 +835,8 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
                                   critic_attention_mask=(tpl != 0).long(), grad_sync=gen_grad_sync)
     else:
         g = generator_update(critic, gen_optimizer, fakes[-1], fake_lengths=lengths[-1])
+    if ahead is not None:
+        ahead.wait_host()  # (the generator is free again when this call returns; the result stays for the next call)
     return c_sum / hp.n_critic, g
 
 

@@ -53,7 +53,8 @@ class Steps:
 
     def set_frozen(self, frozen: bool) -> None: ...
     def set_critic_lr(self, lr: float) -> None: ...
-    def blind_iteration(self, real_batches: Sequence[dict], with_generator_update: bool): ...   # -> (c_loss mean or None, g_loss or None)
+    # -> (c_loss mean or None, g_loss or None); more_follows: another full group comes after this one in the epoch
+    def blind_iteration(self, real_batches: Sequence[dict], with_generator_update: bool, more_follows: bool = False): ...
     def seeded_iteration(self, real_batches: Sequence[dict], gen_batches: Sequence[dict], gen_update_batch: Optional[dict]): ...
     def evaluate(self, tag: str, epoch: int, batch: int, c_loss: float, g_loss: float) -> None: ...
     def save(self, epoch: int) -> None: ...
@@ -75,11 +76,14 @@ def run_epoch_blind(steps: Steps, epoch: int, critic_loader) -> Dict[str, float]
     it = iter(critic_loader)
     mid = len(critic_loader) // 2          # (the reference compares the ITERATION count with half the number of critic batches)
     n_iter, c_sum, g_sum = 0, 0.0, 0.0
+    nxt = _take(it, steps.n_critic)
     while True:
-        group = _take(it, steps.n_critic)
+        group, nxt = nxt, []
         full = len(group) == steps.n_critic
+        if full:
+            nxt = _take(it, steps.n_critic)  # (looked at now: the iteration may start on the next one's fakes if it is whole)
         if group:
-            c, g = steps.blind_iteration(group, with_generator_update=full)
+            c, g = steps.blind_iteration(group, with_generator_update=full, more_follows=len(nxt) == steps.n_critic)
         if not full:
             break  # the loader ran dry inside the group: its critic updates stand, no generator update, epoch over
         c_sum, g_sum = c_sum + c, g_sum + g
@@ -154,6 +158,11 @@ class EngineSteps(Steps):
         self.gen_grad_sync = gen_grad_sync
         self.soft = bool(getattr(args, "soft_generator_update", False))
         self.stacked = not bool(getattr(args, "reference_draw_order", False))
+        # the next iteration's fakes beside this iteration's updates (blind mode, stacked fill, token-id generator update)
+        self.ahead = None
+        if (args.mode == "blind" and self.stacked and not bool(getattr(args, "soft_generator_update", False))
+                and not bool(getattr(args, "no_fill_ahead", False))):
+            self.ahead = T.FillAhead(device)
         if self.soft and not self.stacked:
             raise ValueError("--soft_generator_update needs the stacked fill: drop --reference_draw_order")
         self.n_critic = args.n_critic
@@ -188,14 +197,15 @@ class EngineSteps(Steps):
     def _sync(self):
         return self.grad_sync if self.world > 1 else None
 
-    def blind_iteration(self, real_batches, with_generator_update):
+    def blind_iteration(self, real_batches, with_generator_update, more_follows=False):
         T, hp = self.T, self.hp
         if with_generator_update:
             c, g = T.gan_step_blind(self.generator, self.critic, self.gen_opt, self.critic_opt, list(real_batches), self.pool,
                                     hp, self.args.batch_size, self.device, rng=self.len_rng, grad_sync=self._sync(),
                                     soft_generator_update=self.soft,
                                     gen_grad_sync=self.gen_grad_sync if self.world > 1 else None,
-                                    rank=self.rank, world=self.world, stacked_generation=self.stacked)
+                                    rank=self.rank, world=self.world, stacked_generation=self.stacked,
+                                    fill_ahead=self.ahead, more_follows=more_follows)
             self.updates += len(real_batches)
             return float(c), float(g)
         # the incomplete last group of an epoch: its critic updates only
@@ -281,6 +291,11 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--resume", default=None, help="an epoch_<n> checkpoint directory of a previous run")
+    ap.add_argument("--no_fill_ahead", action="store_true",
+                    help="blind mode: fill an iteration's fake batches at its start.  By default they are filled on a second "
+                         "stream while the previous iteration's updates run (the generator does not change in between); same "
+                         "fakes and losses, except that an evaluation point between two iterations then draws its random "
+                         "numbers after the next iteration's lengths and temperatures instead of before them")
     ap.add_argument("--reference_draw_order", action="store_true",
                     help="fill each fake batch right before the update that uses it, as the reference loop does, so the CPU "
                          "generator hands out temperatures and gradient-penalty alphas in the reference's order.  The default "

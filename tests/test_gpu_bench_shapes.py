@@ -166,6 +166,49 @@ def test_gan_step_blind_stacked_vs_one_after_the_other_bf16(pg, monkeypatch):
     assert abs(out[True][1] - out[False][1]) <= 5e-2 * abs(out[False][1]) + 5e-2, (out[True][1], out[False][1])
 
 
+def test_fill_ahead_gives_the_same_iterations_bf16(pg, monkeypatch):
+    """Three blind-mode iterations (critic batch 8, generator batch 4, S 512, n_critic 2, bf16, 2 layers of ProtBERT's
+    width) with the next iteration's fakes filled on a side stream beside the current updates (train.FillAhead)
+    against the same iterations one after the other: identical fake batches in the same order, the same gradient-
+    penalty alphas, the same losses to rounding (the updates' atomics sum in another order)."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=2)
+    pool = list(range(200, 501))
+    hp = T.GanHyper(n_critic=2, lambda_gp=5.0, max_len=512, gen_batch_blind=4)
+    out = {}
+    for ahead_on in (False, True):
+        gen = pg.Generator(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=0))
+        torch.manual_seed(2)
+        critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=1))
+        gopt = pg.AdamW(gen.parameters(), lr=5e-6)
+        copt = pg.AdamW(critic.parameters(), lr=5e-5)
+        rng, tgen = random.Random(1234), torch.Generator().manual_seed(1234)
+        real = [[T.synthetic_real_batch(8, pool, 512, DEV, rng, tgen) for _ in range(2)] for _ in range(3)]
+        seen = []
+        orig_cu, orig_gu = T.critic_update, T.generator_update
+        monkeypatch.setattr(T, "critic_update", lambda cr, op, rd, am, fd, *a, **k: (seen.append((fd.clone(), k["alpha"].clone())), orig_cu(cr, op, rd, am, fd, *a, **k))[1])
+        monkeypatch.setattr(T, "generator_update", lambda cr, op, fd, *a, **k: (seen.append((fd.clone(), None)), orig_gu(cr, op, fd, *a, **k))[1])
+        torch.manual_seed(99)  # host and device generators
+        ahead = T.FillAhead(DEV) if ahead_on else None
+        losses = []
+        for i in range(3):
+            c, g = T.gan_step_blind(gen, critic, gopt, copt, real[i], pool, hp, 8, DEV, rng=rng, fill_ahead=ahead,
+                                    more_follows=i < 2)
+            losses.append((float(c), float(g)))
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T, "critic_update", orig_cu)
+        monkeypatch.setattr(T, "generator_update", orig_gu)
+        if ahead is not None:
+            assert not ahead.pending()
+        out[ahead_on] = (losses, seen)
+    assert len(out[True][1]) == len(out[False][1]) == 9
+    for (fa, aa), (fb, ab) in zip(out[True][1], out[False][1]):
+        assert torch.equal(fa, fb)
+        assert (aa is None and ab is None) or torch.equal(aa, ab)
+    for (c0, g0), (c1, g1) in zip(out[False][0], out[True][0]):
+        assert abs(c1 - c0) <= 2e-3 * abs(c0) + 1e-4 and abs(g1 - g0) <= 2e-3 * abs(g0) + 1e-3, (out[False][0], out[True][0])
+
+
 def _bench_batches(pg, B, S, seed):
     from protgen_gan_amd import train as T
     rng, tg = random.Random(seed), torch.Generator().manual_seed(seed)

@@ -24,8 +24,9 @@ class Rec:
     def set_critic_lr(self, lr):
         self.log.append(("lr", lr))
 
-    def blind_iteration(self, reals, with_generator_update):
+    def blind_iteration(self, reals, with_generator_update, more_follows=False):
         self.log.append(("blind", tuple(reals), with_generator_update))
+        self.log.append(("more_follows", more_follows))
         return (1.0, 2.0) if with_generator_update else (None, None)
 
     def seeded_iteration(self, reals, gens, last):
@@ -51,6 +52,8 @@ def test_blind_epoch_groups_and_end(pg):
     assert [e for e in s.log if e[0] == "blind"] == [("blind", (0, 1, 2), True), ("blind", (3, 4, 5), True), ("blind", (6,), False)]
     assert [e for e in s.log if e[0] == "eval"] == [("eval", "baseline", 0, 0)]   # "mid" needs iteration 7 // 2 = 3: never reached
     assert stats == {"iterations": 2, "c_loss": 1.0, "g_loss": 2.0}
+    # only an iteration that another WHOLE group follows may start on that group's fakes
+    assert [e[1] for e in s.log if e[0] == "more_follows"] == [True, False, False]
     s = Rec(3, None)
     TC.run_epoch_blind(s, 1, list(range(6)))   # a multiple of n_critic: the epoch ends on an empty group, no partial update
     assert [e[1] for e in s.log if e[0] == "blind"] == [(0, 1, 2), (3, 4, 5)] and not [e for e in s.log if e[0] == "eval"]
