@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--gen-batch", type=int, default=4)
     ap.add_argument("--n-critic", type=int, default=8)
     ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="critic updates made this many rows at a time (same update, the activation memory of the smaller batch)")
     ap.add_argument("--lambda-gp", type=float, default=5.0)
     ap.add_argument("--layers", type=int, default=30, help="(debug only) fewer layers invalidates the number")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
@@ -123,7 +125,8 @@ def main():
     if args.regime == "frozen":
         pgt.freeze_protbert(generator)
         pgt.freeze_protbert(critic)
-    hp = pgt.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.seq, gen_batch_blind=args.gen_batch)
+    hp = pgt.GanHyper(n_critic=args.n_critic, lambda_gp=args.lambda_gp, max_len=args.seq, gen_batch_blind=args.gen_batch,
+                      micro_batch=args.micro_batch or None)
     gen_opt = pg.AdamW(generator.parameters(), lr=5e-6, betas=(0.9, 0.999), weight_decay=0.01)
     critic_opt = pg.AdamW(critic.parameters(), lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
     sync = pgd.GradSync([critic.protbert.store, critic.classifier.store], world, overlap=critic.protbert,
@@ -332,7 +335,7 @@ def main():
                                  else "configs[1] at other sizes") +
                                 ": one blind-mode GAN step (fully_masked_train.py), ProtBERT generator + ProtBERT critic head"),
                    "critic_batch": args.batch, "generator_batch": args.gen_batch if seeds is None else args.batch, "seq_len": args.seq, "n_critic": args.n_critic,
-                   "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime,
+                   "lambda_gp": args.lambda_gp, "layers": args.layers, "regime": args.regime, "micro_batch": args.micro_batch or None,
                    "generator_update": "soft embeddings through the critic's 3-D branch" if soft else "token ids (reference loop)",
                    "fill_iterations_per_fake_batch": 10, "parallelism": f"dp{world}",
                    "weights": "ProtBERT architecture, seeded random init", "lengths": f"uniform {pool[0]}..{pool[-1]} (DNMT-length stand-in)"},

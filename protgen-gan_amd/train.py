@@ -62,6 +62,7 @@ class GanHyper:
     max_len: int = 512                  # :60, :309
     gen_batch_blind: int = 4            # :339
     warmup_head_lr: float = 1e-5        # :124
+    micro_batch: Optional[int] = None   # critic updates made this many rows at a time (critic_update; no counterpart)
 
 
 def sample_sequence_length(length_pool: Sequence[int], variation: float = 0.1, rng=random) -> int:
@@ -260,7 +261,7 @@ def generate_fake_batches(generator: Generator, lengths_per_batch: Sequence[Sequ
 
 def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask_real, fake, fake_mask, hp: GanHyper,
                                grad_sync, alpha, ragged=False, real_lengths=None, fake_lengths=None,
-                               train_encoder=True) -> Optional[torch.Tensor]:
+                               train_encoder=True, part=None) -> Optional[torch.Tensor]:
     """The critic update with ONE encoder forward over 3B sequences: the gradient-penalty interpolates
     (loss.py:22-66) and the real and fake rows (fully_masked_train.py:321-323) use the same weights, and at
     B = 8 a forward over 4096 or 8192 token rows runs at little more than half the rate of one over 12 288.
@@ -269,9 +270,15 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     score backward on the other 2B, tangent and second-order passes on the first B.
 
     `train_encoder=False` (the trainers' first epoch: encoder frozen, the head learns) exists in the ragged form
-    only; None is returned when that form does not apply and nothing has been done."""
+    only; None is returned when that form does not apply and nothing has been done.
+
+    `part = (rows of the whole batch, is first, is last)`: these rows are one slice of a larger batch whose update
+    is made slice by slice (critic_update's micro_batch).  The losses are means over the whole batch, so a slice
+    enters with the whole batch's 1 / B; gradients add up across the slices; the first slice clears them, the last
+    one reduces them across ranks and steps the optimizer.  The return value is this slice's share of c_loss."""
     m, head = critic.protbert, critic.classifier
     B, S = real.shape
+    Btot, first, last = part if part is not None else (B, True, True)
     H = m.config.hidden_size
     cd = m.compute_dtype
     dt = ops.dt_code(cd)
@@ -281,7 +288,8 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     rmask = attn_mask_real.to(dev)
     if not train_encoder and not (ragged and ONE_BACKWARD_DEFAULT and S % 8 == 0):
         return None
-    critic_optimizer.zero_grad()
+    if first:
+        critic_optimizer.zero_grad()
     if alpha is None:
         alpha = torch.rand(B, 1, 1)
     alpha = alpha.to(device=dev, dtype=torch.float32).contiguous().view(B)
@@ -295,7 +303,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
         if sum(lens_j) + sum(lens_rf) < 3 * B * S or not train_encoder:
             return _critic_update_ragged(critic, critic_optimizer, real, rmask.to(torch.float32), fake,
                                          fake_mask.to(torch.float32), joint, lens_j, lens_rf[:B], lens_rf[B:], hp, grad_sync,
-                                         alpha, train_encoder)
+                                         alpha, train_encoder, part=(Btot, first, last))
     mask3 = torch.cat([joint, rmask.to(torch.float32), fake_mask.to(torch.float32)], dim=0).contiguous()
     _note_rows("critic", [S] * B, [S] * (2 * B))
 
@@ -318,7 +326,7 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
     m.store.begin_accumulate()
     head.store.begin_accumulate()
     ghead = head.store.grad
-    w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
+    w = torch.cat([torch.full((B,), -1.0 / Btot), torch.full((B,), 1.0 / Btot)]).to(dev)
     norms = torch.empty(B, dtype=torch.float32, device=dev)
     gp = torch.empty((), dtype=torch.float32, device=dev)
     joint = joint.contiguous()
@@ -350,11 +358,12 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
                                    ghead.data_ptr(), dh2.data_ptr(), S * H, st), "pg_head_backward")
         dx2 = m._encode_backward(stash, dh2, 2 * B, S, param_grads=True, stash_rows=3 * B, row0=B)
     check(lib.pg_gp_norms(dt, g.data_ptr(), joint.data_ptr(), B, S, H, norms.data_ptr(), gp.data_ptr(), st), "pg_gp_norms")
-    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
+    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam) * (B / Btot)
     m._embed_backward(real, sum_r, dx2[:B])
     m._embed_backward(fake, sum_f, dx2[B:])
     # penalty direction, tangent pass, second-order pass (loss.py's create_graph backward)
-    scale = torch.full((), lam, dtype=torch.float32, device=dev)
+    # (the direction kernel divides by the rows it is given: a slice of a larger batch is rescaled to the batch's 2 / B)
+    scale = torch.full((), lam * B / Btot, dtype=torch.float32, device=dev)
     v = torch.empty_like(g)
     check(lib.pg_gp_direction(dt, g.data_ptr(), joint.data_ptr(), norms.data_ptr(), B, S, H, scale.data_ptr(), v.data_ptr(),
                               None, st), "pg_gp_direction")
@@ -370,14 +379,15 @@ def _critic_update_one_forward(critic: Critic, critic_optimizer, real, attn_mask
           "pg_interpolate_bwd")
     m._embed_backward(real, sum_r, d_r)
     m._embed_backward(fake, sum_f, d_f)
-    if grad_sync is not None:
-        grad_sync()
-    critic_optimizer.step()
+    if last:
+        if grad_sync is not None:
+            grad_sync()
+        critic_optimizer.step()
     return c_loss.detach()
 
 
 def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, fake_mask, joint, lens_j, lens_r, lens_f,
-                          hp: GanHyper, grad_sync, alpha, train_encoder=True) -> torch.Tensor:
+                          hp: GanHyper, grad_sync, alpha, train_encoder=True, part=None) -> torch.Tensor:
     """_critic_update_one_forward over ragged rows: sequence b of the interpolates, of the real and of the fake
     batch runs on its lens_j[b] / lens_r[b] / lens_f[b] leading columns (lens_j[b] <= both others), all 3B
     sequences laid back to back.  Columns left out are hidden by the masks in every pass of the reference
@@ -389,6 +399,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     no second-order pass, no embedding backward."""
     m, head = critic.protbert, critic.classifier
     B, S = real.shape
+    Btot, _, last = part if part is not None else (B, True, True)
     H = m.config.hidden_size
     cd = m.compute_dtype
     dt = ops.dt_code(cd)
@@ -426,7 +437,7 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
         m.store.begin_accumulate()
     head.store.begin_accumulate()
     ghead = head.store.grad
-    w = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(dev)
+    w = torch.cat([torch.full((B,), -1.0 / Btot), torch.full((B,), 1.0 / Btot)]).to(dev)
     norms = torch.empty(B, dtype=torch.float32, device=dev)
     gp = torch.empty((), dtype=torch.float32, device=dev)
     dcls = torch.empty(3 * B, H, dtype=cd, device=dev)
@@ -449,9 +460,9 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
         g = m._encode_backward(stash, dhj, B, S, param_grads=False, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
     check(lib.pg_gp_norms_ragged(dt, g.data_ptr(), mask3.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H, norms.data_ptr(),
                                  gp.data_ptr(), st), "pg_gp_norms_ragged")
-    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam)
+    c_loss = critic_loss(scores[B:2 * B], scores[2 * B:], gp, lam) * (B / Btot)
     # penalty direction, tangent pass, second-order pass (loss.py's create_graph backward) on the first B sequences
-    scale = torch.full((), lam, dtype=torch.float32, device=dev)
+    scale = torch.full((), lam * B / Btot, dtype=torch.float32, device=dev)
     v = torch.empty_like(g)
     check(lib.pg_gp_direction_ragged(dt, g.data_ptr(), mask3.data_ptr(), norms.data_ptr(), rgJ.seq_off.data_ptr(), B, S, H,
                                      scale.data_ptr(), v.data_ptr(), None, st), "pg_gp_direction_ragged")
@@ -462,9 +473,10 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     check(lib.pg_head_jvp_grad(dt, head.store.master.data_ptr(), hstash.data_ptr(), hdot_cls.data_ptr(), H, B, H, 1.0,
                                ghead.data_ptr(), tstash.data_ptr(), None, st), "pg_head_jvp_grad")
     if not train_encoder:
-        if grad_sync is not None:
-            grad_sync()
-        critic_optimizer.step()
+        if last:
+            if grad_sync is not None:
+                grad_sync()
+            critic_optimizer.step()
         return c_loss.detach()
     xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0, adj_rows=3 * B, rgd=rgd, T=Tj)
     # the interpolates' input gradient joins the real and fake rows' own (loss.py:29), then one embedding backward
@@ -472,16 +484,17 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
                                         rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H,
                                         1, st), "pg_interpolate_bwd_ragged")
     m._embed_backward_packed(ids_rf, rgRF.pos, sums, dx2)
-    if grad_sync is not None:
-        grad_sync()
-    critic_optimizer.step()
+    if last:
+        if grad_sync is not None:
+            grad_sync()
+        critic_optimizer.step()
     return c_loss.detach()
 
 
 def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, fake_data, hp: GanHyper,
                   pad_id=0, grad_sync: Optional[Callable[[], None]] = None, alpha=None,
                   one_forward: Optional[bool] = None, real_lengths=None, fake_lengths=None,
-                  ragged: Optional[bool] = None) -> torch.Tensor:
+                  ragged: Optional[bool] = None, micro_batch: Optional[int] = None) -> torch.Tensor:
     """fully_masked_train.py:297-326 / 10p_train.py:327-338.  `grad_sync` (data-parallel
     gradient averaging) runs between backward and the optimizer step.  Returns c_loss
     (device scalar; the caller decides when to synchronise for logging).
@@ -493,7 +506,12 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
     `ragged` (default on, with one_forward): every row runs on its leading columns up to the last one its mask
     shows, see _critic_update_ragged.  `real_lengths` / `fake_lengths`: per row, an upper bound of that column
     count known on the host (the tokenizer's lengths, the fake templates' lengths); without them the masks are
-    read back once (one device-to-host copy per update)."""
+    read back once (one device-to-host copy per update).
+
+    `micro_batch` (with one_forward): the update is made `micro_batch` rows at a time, gradients summed, one
+    optimizer step at the end: the same update (losses are batch means, the penalty is per sample) with the
+    activation memory of the smaller batch.  Three stashes of a 30-layer pass over 3 x 32 sequences of 1024 tokens do
+    not fit one GPU's 288 GB; at 8 rows they take about 60 GB."""
     fake = fake_data.detach()
     fake_mask = (fake != pad_id).long()
     head_trains = critic.classifier[0].weight.requires_grad
@@ -520,6 +538,19 @@ def critic_update(critic: Critic, critic_optimizer, real_data, attn_mask_real, f
             raise ValueError(f"real {tuple(real.shape)} and fake {tuple(fk.shape)} batches differ in shape")
         if ragged is None:
             ragged = RAGGED_DEFAULT
+        B = real.size(0)
+        if micro_batch and 0 < micro_batch < B:
+            if alpha is None:
+                alpha = torch.rand(B, 1, 1)  # (one draw for the whole batch, as loss.py:15 makes it)
+            total = None
+            for lo in range(0, B, micro_batch):
+                hi = min(B, lo + micro_batch)
+                c = _critic_update_one_forward(
+                    critic, critic_optimizer, real[lo:hi], attn_mask_real[lo:hi], fk[lo:hi], fake_mask[lo:hi], hp, grad_sync,
+                    alpha[lo:hi], ragged, real_lengths[lo:hi] if real_lengths is not None else None,
+                    fake_lengths[lo:hi] if fake_lengths is not None else None, part=(B, lo == 0, hi == B))
+                total = c if total is None else total + c
+            return total
         return _critic_update_one_forward(critic, critic_optimizer, real, attn_mask_real, fk, fake_mask, hp, grad_sync, alpha,
                                           ragged, real_lengths, fake_lengths)
     critic_optimizer.zero_grad()
@@ -822,7 +853,8 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     for batch, fake, alpha, fl in zip(real_batches, fakes, alphas, lengths):
         # (a fake row's non-pad columns end inside its template: positions past it are never masks, so never filled)
         c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
-                          grad_sync=grad_sync, alpha=alpha, real_lengths=batch.get("lengths"), fake_lengths=fl)
+                          grad_sync=grad_sync, alpha=alpha, real_lengths=batch.get("lengths"), fake_lengths=fl,
+                          micro_batch=hp.micro_batch)
         c_sum = c if c_sum is None else c_sum + c
     if soft_generator_update:
         tpl = blind_template([min(L, hp.max_len) for L in lengths[-1]], device)
@@ -855,7 +887,8 @@ def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_
         for batch, fake, gb in zip(real_batches[:hp.n_critic], fakes, gen_batches):
             # (a seeded fake keeps the pad columns of the sequence it started from)
             c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
-                              grad_sync=grad_sync, real_lengths=batch.get("lengths"), fake_lengths=gb.get("lengths"))
+                              grad_sync=grad_sync, real_lengths=batch.get("lengths"), fake_lengths=gb.get("lengths"),
+                              micro_batch=hp.micro_batch)
             c_sum = c if c_sum is None else c_sum + c
         if soft_generator_update:
             # the generator batch masked as a fill would mask it (10p_train.py:137-145), one pass, keys `ids != PAD`

@@ -209,6 +209,38 @@ def test_fill_ahead_gives_the_same_iterations_bf16(pg, monkeypatch):
         assert abs(c1 - c0) <= 2e-3 * abs(c0) + 1e-4 and abs(g1 - g0) <= 2e-3 * abs(g0) + 1e-3, (out[False][0], out[True][0])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_micro_batched_critic_update_is_the_same_update(pg, dtype):
+    """critic_update(micro_batch=3) on 8 rows (slices of 3, 3 and 2) against the update in one piece: the same loss and
+    the same gradients (fp32: to rounding of the sums; bf16: different tile kernels for the different row counts)."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=3)
+    real, fake, alpha = _bench_batches(pg, 8, 256, 11)
+    out = {}
+    for mb in (None, 3):
+        torch.manual_seed(3)
+        critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=dtype).init_random(seed=2))
+        steps = []
+
+        class Opt(_NoStep):
+            def step(self):
+                steps.append(1)
+
+        loss = T.critic_update(critic, Opt(critic), real["input_ids"], real["attention_mask"], fake, T.GanHyper(lambda_gp=5.0, max_len=256),
+                               alpha=alpha, real_lengths=real["lengths"], micro_batch=mb)
+        torch.cuda.synchronize()
+        assert len(steps) == 1
+        out[mb] = (float(loss), _grads(critic))
+    (l0, g0), (l1, g1) = out[None], out[3]
+    tol_l, tol_g = (1e-5, 2e-4) if dtype == torch.float32 else (2e-3, 5e-2)
+    assert abs(l1 - l0) <= tol_l * abs(l0) + 1e-6, (l0, l1)
+    assert g0.keys() == g1.keys()
+    typical = sorted(float(v.norm()) for v in g0.values())[len(g0) // 2]
+    dist = {n: rel_l2(g1[n].numpy(), g0[n].numpy()) for n in g0 if float(g0[n].norm()) > 0.05 * typical and "key.bias" not in n}
+    worst = max(dist.items(), key=lambda kv: kv[1])
+    assert worst[1] < tol_g, worst
+
+
 def _bench_batches(pg, B, S, seed):
     from protgen_gan_amd import train as T
     rng, tg = random.Random(seed), torch.Generator().manual_seed(seed)
