@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-fill-ahead", action="store_true",
                     help="fill an iteration's fake batches at its start instead of beside the previous iteration's updates "
                          "(train.FillAhead; blind mode with the reference's generator update only)")
+    ap.add_argument("--no-boost", action="store_true", help="(A/B) with the fill beside the updates: updates on the caller's stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
     ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
@@ -170,7 +171,8 @@ def main():
 
     # the next iteration's fakes are filled on a side stream beside this iteration's updates (every timed step still
     # runs one whole fill and one whole set of updates; what step i consumes was filled during step i - 1)
-    ahead = pgt.FillAhead(dev) if (seeds is None and not soft and not args.no_fill_ahead) else None
+    ahead = (pgt.FillAhead(dev, boost_updates=not args.no_boost) if (seeds is None and not soft and not args.no_fill_ahead)
+             else None)
 
     def one_step(i, ahead=ahead):
         if seeds is not None:

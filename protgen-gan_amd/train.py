@@ -705,11 +705,15 @@ class FillAhead:
     device generator in fill order.  So the fake batches, the alphas and with them every loss are the ones the
     one-iteration-at-a-time schedule produces.  Not for the soft generator update (it changes the generator)."""
 
-    def __init__(self, device):
+    def __init__(self, device, boost_updates: bool = True):
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(self.device)
+        # The updates are the longer of the two and a chain of dependent launches; the fill is there to take what they
+        # leave.  With `boost_updates` an iteration's updates are issued on a stream of higher priority than the
+        # fill's (ordered behind and before the caller's stream), so a freed CU goes to the updates first.
+        self.update_stream = torch.cuda.Stream(self.device, priority=-1) if boost_updates else None
         self._thread: Optional[threading.Thread] = None
         self._out = None
         self._err: Optional[BaseException] = None
@@ -732,7 +736,9 @@ class FillAhead:
             except BaseException as e:  # noqa: BLE001  (re-raised in the main thread by take / wait_host)
                 self._err = e
 
-        self._thread = threading.Thread(target=run, name="protgen-fill-ahead", daemon=True)
+        # (not a daemon: an interpreter that exits on an error elsewhere waits for the fill instead of tearing the device
+        # runtime down under it)
+        self._thread = threading.Thread(target=run, name="protgen-fill-ahead")
         self._thread.start()
 
     def wait_host(self):
@@ -849,6 +855,29 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     if ahead is not None and more_follows:
         nl, nt, na = draw_plan(hp.n_critic, batch_size)
         ahead.start(lambda: (nl, nt, na, generate_fake_batches(generator, nl, nt, hp, device)))
+    boost = ahead.update_stream if (ahead is not None and ahead.pending()) else None
+    if boost is not None:
+        caller = torch.cuda.current_stream(boost.device)
+        boost.wait_stream(caller)
+        for f in fakes:
+            f.record_stream(boost)
+        with torch.cuda.stream(boost):
+            c, g = _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths,
+                                  temps, hp, device, grad_sync, soft_generator_update, gen_grad_sync)
+        caller.wait_stream(boost)
+        for t in (c, g):
+            t.record_stream(caller)
+    else:
+        c, g = _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths,
+                              temps, hp, device, grad_sync, soft_generator_update, gen_grad_sync)
+    if ahead is not None:
+        ahead.wait_host()  # (the generator is free again when this call returns; the result stays for the next call)
+    return c, g
+
+
+def _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths, temps, hp, device,
+                   grad_sync, soft_generator_update, gen_grad_sync):
+    """The n_critic critic updates and the generator update of one blind-mode iteration, on the current stream."""
     c_sum = None
     for batch, fake, alpha, fl in zip(real_batches, fakes, alphas, lengths):
         # (a fake row's non-pad columns end inside its template: positions past it are never masks, so never filled)
@@ -867,8 +896,6 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
                                   critic_attention_mask=(tpl != 0).long(), grad_sync=gen_grad_sync)
     else:
         g = generator_update(critic, gen_optimizer, fakes[-1], fake_lengths=lengths[-1])
-    if ahead is not None:
-        ahead.wait_host()  # (the generator is free again when this call returns; the result stays for the next call)
     return c_sum / hp.n_critic, g
 
 
