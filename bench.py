@@ -89,7 +89,6 @@ def main():
     ap.add_argument("--no-fill-ahead", action="store_true",
                     help="fill an iteration's fake batches at its start instead of beside the previous iteration's updates "
                          "(train.FillAhead; blind mode with the reference's generator update only)")
-    ap.add_argument("--no-boost", action="store_true", help="(A/B) with the fill beside the updates: updates on the caller's stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
     ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
@@ -161,8 +160,10 @@ def main():
 
     seeds = None
     if args.gan_mode == "seeded":
+        # (one set more than iterations: with the fill run ahead, the last timed iteration fills for a next one too, so
+        # that the timed region holds as many fills as iterations)
         seeds = [[pgt.synthetic_real_batch(args.batch, pool, args.seq, dev, rng, tgen, rank, world) for _ in range(args.n_critic + 1)]
-                 for _ in range(total)]
+                 for _ in range(total + 1)]
 
     soft = args.soft_generator_update
     gen_sync = None
@@ -171,13 +172,14 @@ def main():
 
     # the next iteration's fakes are filled on a side stream beside this iteration's updates (every timed step still
     # runs one whole fill and one whole set of updates; what step i consumes was filled during step i - 1)
-    ahead = (pgt.FillAhead(dev, boost_updates=not args.no_boost) if (seeds is None and not soft and not args.no_fill_ahead)
-             else None)
+    ahead = pgt.FillAhead(dev) if (not soft and not args.no_fill_ahead) else None
 
     def one_step(i, ahead=ahead):
         if seeds is not None:
+            nxt = seeds[i + 1] if (ahead is not None and i + 1 < len(seeds)) else None
             return pgt.gan_step_seeded(generator, critic, gen_opt, critic_opt, real[i], seeds[i], hp,
-                                       grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync)
+                                       grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync,
+                                       fill_ahead=ahead, next_gen_batches=nxt)
         return pgt.gan_step_blind(generator, critic, gen_opt, critic_opt, real[i], pool, hp, args.batch, dev, rng=rng,
                                   grad_sync=sync if use_sync else None, soft_generator_update=soft, gen_grad_sync=gen_sync,
                                   rank=rank, world=world, fill_ahead=ahead)

@@ -145,7 +145,8 @@ def generate_fakes_for_batch(generator: Generator, input_ids: torch.Tensor, hp: 
 
 def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tensor], hp: GanHyper, mask_id=4, cls_id=2,
                                sep_id=3, pad_id=0, unk_id=1, packed: bool = True,
-                               random_masks: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+                               random_masks: Optional[Sequence[torch.Tensor]] = None,
+                               temps_per_batch: Optional[Sequence[Sequence[float]]] = None) -> List[torch.Tensor]:
     """Seeded-mode fakes for several real batches at once (the generator does not change between the
     critic updates of one iteration): every batch is masked as generate_fakes_for_batch masks it (its own
     device draw for the 90 % mask, its own CPU draw of a temperature per fill iteration, in batch order),
@@ -157,6 +158,7 @@ def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tens
     S = inputs[0].size(1)
     if any(x.size(1) != S for x in inputs):
         raise ValueError("seeded batches must share one padded width")
+    given_temps = temps_per_batch  # (drawn by the caller: a fill on a second host thread must leave the CPU generator alone)
     parts, temps_per_batch, spans, r = [], [], [], 0
     for bi, x in enumerate(inputs):
         meaningful = (x != pad_id) & (x != unk_id) & (x != cls_id) & (x != sep_id)
@@ -165,7 +167,7 @@ def generate_fakes_for_batches(generator: Generator, inputs: Sequence[torch.Tens
         ids = x.clone()
         ids[meaningful & random_mask] = mask_id
         parts.append(ids)
-        temps_per_batch.append(fill_temperatures(hp))
+        temps_per_batch.append(fill_temperatures(hp) if given_temps is None else list(given_temps[bi]))
         spans.append((r, r + x.size(0)))
         r += x.size(0)
     ids = torch.cat(parts, dim=0).contiguous()
@@ -705,15 +707,11 @@ class FillAhead:
     device generator in fill order.  So the fake batches, the alphas and with them every loss are the ones the
     one-iteration-at-a-time schedule produces.  Not for the soft generator update (it changes the generator)."""
 
-    def __init__(self, device, boost_updates: bool = True):
+    def __init__(self, device):
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(self.device)
-        # The updates are the longer of the two and a chain of dependent launches; the fill is there to take what they
-        # leave.  With `boost_updates` an iteration's updates are issued on a stream of higher priority than the
-        # fill's (ordered behind and before the caller's stream), so a freed CU goes to the updates first.
-        self.update_stream = torch.cuda.Stream(self.device, priority=-1) if boost_updates else None
         self._thread: Optional[threading.Thread] = None
         self._out = None
         self._err: Optional[BaseException] = None
@@ -855,21 +853,8 @@ def gan_step_blind(generator: Generator, critic: Critic, gen_optimizer, critic_o
     if ahead is not None and more_follows:
         nl, nt, na = draw_plan(hp.n_critic, batch_size)
         ahead.start(lambda: (nl, nt, na, generate_fake_batches(generator, nl, nt, hp, device)))
-    boost = ahead.update_stream if (ahead is not None and ahead.pending()) else None
-    if boost is not None:
-        caller = torch.cuda.current_stream(boost.device)
-        boost.wait_stream(caller)
-        for f in fakes:
-            f.record_stream(boost)
-        with torch.cuda.stream(boost):
-            c, g = _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths,
-                                  temps, hp, device, grad_sync, soft_generator_update, gen_grad_sync)
-        caller.wait_stream(boost)
-        for t in (c, g):
-            t.record_stream(caller)
-    else:
-        c, g = _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths,
-                              temps, hp, device, grad_sync, soft_generator_update, gen_grad_sync)
+    c, g = _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batches, fakes, alphas, lengths,
+                          temps, hp, device, grad_sync, soft_generator_update, gen_grad_sync)
     if ahead is not None:
         ahead.wait_host()  # (the generator is free again when this call returns; the result stays for the next call)
     return c, g
@@ -901,13 +886,42 @@ def _blind_updates(critic, generator, gen_optimizer, critic_optimizer, real_batc
 
 def gan_step_seeded(generator: Generator, critic: Critic, gen_optimizer, critic_optimizer,
                     real_batches: List[dict], gen_batches: List[dict], hp: GanHyper, grad_sync=None,
-                    stacked_generation: bool = True, soft_generator_update: bool = False, gen_grad_sync=None):
+                    stacked_generation: bool = True, soft_generator_update: bool = False, gen_grad_sync=None,
+                    fill_ahead: Optional[FillAhead] = None, next_gen_batches: Optional[List[dict]] = None):
     """One iteration of the seeded-mode loop (10p_train.py:296-370): needs n_critic critic
     batches and n_critic + 1 generator batches.  With `stacked_generation` the n_critic + 1 fake
-    batches are filled up front as one stacked batch (generate_fakes_for_batches)."""
+    batches are filled up front as one stacked batch (generate_fakes_for_batches).
+
+    `fill_ahead` + `next_gen_batches` (stacked form, token-id generator update): the fakes grown from the NEXT
+    iteration's generator batches are filled on the side stream beside this iteration's updates, and this iteration
+    takes the ones a previous call left there (FillAhead).  The next iteration's temperatures are then drawn from
+    the CPU generator before this iteration's gradient-penalty alphas instead of after them."""
     c_sum = None
     if soft_generator_update and not stacked_generation:
         raise ValueError("the soft generator update is wired into the stacked form only")
+    if stacked_generation and fill_ahead is not None and not soft_generator_update:
+        n_fill = hp.n_critic + 1
+        fakes = fill_ahead.take()
+        if fakes is None:
+            fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:n_fill]], hp)
+        if next_gen_batches is not None:
+            ins = [gb["input_ids"] for gb in next_gen_batches[:n_fill]]
+            temps = [fill_temperatures(hp) for _ in ins]
+            fill_ahead.start(lambda: generate_fakes_for_batches(generator, ins, hp, temps_per_batch=temps))
+
+        def updates():
+            total = None
+            for batch, fake, gb in zip(real_batches[:hp.n_critic], fakes, gen_batches):
+                c = critic_update(critic, critic_optimizer, batch["input_ids"], batch["attention_mask"], fake, hp,
+                                  grad_sync=grad_sync, real_lengths=batch.get("lengths"), fake_lengths=gb.get("lengths"),
+                                  micro_batch=hp.micro_batch)
+                total = c if total is None else total + c
+            return total / hp.n_critic, generator_update(critic, gen_optimizer, fakes[hp.n_critic],
+                                                         fake_lengths=gen_batches[hp.n_critic].get("lengths"))
+
+        c, g = updates()
+        fill_ahead.wait_host()
+        return c, g
     if stacked_generation:
         n_fill = hp.n_critic + (0 if soft_generator_update else 1)
         fakes = generate_fakes_for_batches(generator, [gb["input_ids"] for gb in gen_batches[:n_fill]], hp)
