@@ -113,8 +113,8 @@ def test_critic_update_full_size_bf16_b2_s512_vs_oracle(pg, full):
     with torch.no_grad():
         rs_h, fs_h = critic(d(real), attention_mask=d(ones)), critic(d(fake), attention_mask=d(ones))
     l_h = pg.critic_loss(rs_h, fs_h, gp_h, 5.0)
-    rel_close(float(gp_h), float(gp), 2e-2, "gp")
-    rel_close(float(l_h), float(loss), 2e-2, "c_loss")
+    rel_close(float(gp_h.detach()), float(gp.detach()), 2e-2, "gp")
+    rel_close(float(l_h.detach()), float(loss.detach()), 2e-2, "c_loss")
     # the CLS hidden state of both batches, engine against oracle, and the head's Jacobian there
     x = torch.cat([real, fake])
     with torch.no_grad():
