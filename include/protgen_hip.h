@@ -463,6 +463,10 @@ int pg_mlm_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, cons
  * d_hidden / dx_out / xdot_in / hdot_out / xbar_out hold this pass's T = seq_off[B] - seq_off[0] token rows.  */
 #define PG_BWD_PARAM_GRADS 1
 #define PG_BWD_SAVE_ADJOINTS 2
+/* pg_encoder_backward2 only: before layer l writes any parameter gradient, the stream waits for layer_done[l] as an
+ * earlier pass recorded it (a first-order backward over other rows of the same update that runs on another stream
+ * and adds into the same gradient buffers); the pass then records the events anew as it goes. */
+#define PG_BWD_WAIT_LAYER_DONE 4
 int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, int dtype, int B, int S, const void* stash,
                         void* d_hidden, const float* mask, int flags, void* adj_stash, void* dx_out,
                         void* workspace, int64_t workspace_bytes, void* stream, void* const* layer_done,

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PG_LIB") or os.path.join(HERE, "libprotgen_hip.so")
 
 PG_F32, PG_BF16 = 0, 1
 PG_ACT_NONE, PG_ACT_GELU, PG_ACT_MUL_DGELU = 0, 1, 2
-PG_BWD_PARAM_GRADS, PG_BWD_SAVE_ADJOINTS = 1, 2
+PG_BWD_PARAM_GRADS, PG_BWD_SAVE_ADJOINTS, PG_BWD_WAIT_LAYER_DONE = 1, 2, 4
 
 # enum order of include/protgen_hip.h
 P_WORD_EMB, P_POS_EMB, P_TYPE_EMB, P_EMB_LN_G, P_EMB_LN_B, P_MLM_BIAS, P_MLM_W, P_MLM_B, P_MLM_LN_G, P_MLM_LN_B = range(10)

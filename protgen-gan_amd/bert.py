@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._lib import PG_BWD_PARAM_GRADS, PG_BWD_SAVE_ADJOINTS, check, lib
+from ._lib import PG_BWD_PARAM_GRADS, PG_BWD_SAVE_ADJOINTS, PG_BWD_WAIT_LAYER_DONE, check, lib
 
 
 # ----------------------------------------------------------------------------- config
@@ -717,15 +717,22 @@ class ProtBertForMaskedLM(nn.Module):
               "pg_encoder_jvp")
         return hdot
 
-    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0, adj_rows=0, rgd=None, T=None):
+    def _encode_backward2(self, stash, adj, tan, B, S, want_xbar=True, stash_rows=0, row0=0, adj_rows=0, rgd=None, T=None,
+                          wait_layer_events=False):
+        """`wait_layer_events`: every layer waits for its "gradients issued" event as a first-order backward on another
+        stream recorded it, before it adds into the same gradient buffers."""
         dt = ops.dt_code(self.compute_dtype)
         ws, n = self._ws(B, S, T if rgd is not None else None)
         H = self.config.hidden_size
         shape = (T, H) if rgd is not None else (B, S, H)
         xbar = torch.empty(*shape, dtype=self.compute_dtype, device=self.device) if want_xbar else None
         pr = _params_struct(self.store, self.compute_dtype, True)
+        flags = PG_BWD_PARAM_GRADS
+        if wait_layer_events:
+            self.enable_layer_events()
+            flags |= PG_BWD_WAIT_LAYER_DONE
         check(lib.pg_encoder_backward2(C.byref(self._ccfg), C.byref(pr), dt, B, S, stash.data_ptr(), adj.data_ptr(),
-                                       tan.data_ptr(), PG_BWD_PARAM_GRADS, ops.ptr(xbar), ws.data_ptr(), n, ops.stream(),
+                                       tan.data_ptr(), flags, ops.ptr(xbar), ws.data_ptr(), n, ops.stream(),
                                        self._layer_event_arr, stash_rows, row0, adj_rows,
                                        C.byref(rgd) if rgd is not None else None),
               "pg_encoder_backward2")

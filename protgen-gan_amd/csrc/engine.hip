@@ -837,7 +837,9 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
   // adjoints of a pass over adj_rows >= B sequences, of which this pass's are the first
   if (!make_view(cfg, dtype, d, rag, adj_rows, 0, rg ? rg->adj_T : 0, 0, sva)) return PG_ERR_ARG;
   const bool grads = flags & PG_BWD_PARAM_GRADS;
+  const bool wait_done = (flags & PG_BWD_WAIT_LAYER_DONE) && grads;
   if (grads && !p->grad) return PG_ERR_ARG;
+  if (wait_done && !layer_done) return PG_ERR_ARG;
   if (dtype == PG_BF16 && !p->shadow) return PG_ERR_ARG;
   const int epc = dtype == PG_F32 ? 4 : 8;
   if (S % epc) return PG_ERR_UNSUPPORTED;
@@ -861,6 +863,9 @@ extern "C" int pg_encoder_backward2(const pg_model_cfg* cfg, const pg_params* p,
     char* xbar = (ybar == w.x0) ? w.x1 : w.x0;
     const int r = (d.L - 1 - l) % dwq.depth;
     char* const wf = w.rf[r]; char* const wu = w.ru[r]; char* const wqkv = w.rqkv[r]; char* const wa = w.ra[r];
+    // (the other pass's record of this layer's event is still its latest: this pass records event l only after the
+    // weight-gradient launch that contains layer l, which comes later on this stream)
+    if (wait_done && hipStreamWaitEvent(st, (hipEvent_t)layer_done[l], 0) != hipSuccess) return PG_ERR_LAUNCH;
     // LN2: fbar
     CK(pg_layernorm_bwd2(dtype, s.f, t.f, a.y, ybar, pv.m(pv.lo(l, PG_L_LN2_G)), cfg->ln_eps, wf,
                          grads ? pv.g(pv.lo(l, PG_L_LN2_G)) : nullptr, grads ? pv.g(pv.lo(l, PG_L_LN2_B)) : nullptr,

@@ -32,6 +32,18 @@ ONE_FORWARD_DEFAULT = os.environ.get("PG_ONE_FORWARD", "1") != "0"
 ONE_BACKWARD_DEFAULT = os.environ.get("PG_ONE_BACKWARD", "1") != "0"
 # with one forward: every row runs on its own leading columns up to the last one its mask shows (PG_RAGGED=0: all S)
 RAGGED_DEFAULT = os.environ.get("PG_RAGGED", "1") != "0"
+# ragged update: the real and fake rows' backward on a second stream beside the interpolates' three passes
+# (PG_TWO_STREAM_BACKWARD=0: one first-order backward over all 3B sequences, then the other two passes)
+TWO_STREAM_BACKWARD_DEFAULT = os.environ.get("PG_TWO_STREAM_BACKWARD", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """One extra stream per (device, stream it serves): the second lane of a critic update."""
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
 
 
 # Throughput bookkeeping: the sequence lengths every update actually ran, appended as
@@ -445,8 +457,31 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
     dcls = torch.empty(3 * B, H, dtype=cd, device=dev)
     check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash.data_ptr(), None, B, H, None, dcls.data_ptr(), H, st),
           "pg_head_backward")
-    rgd = rg3.desc(0, B, stash_T=T3, adj_T=T3)
-    if train_encoder:
+    two_streams = train_encoder and TWO_STREAM_BACKWARD_DEFAULT
+    rgd = rg3.desc(0, B, stash_T=T3, adj_T=Tj if two_streams else T3)
+    side = None
+    if two_streams:
+        # Two lanes.  The real and fake rows need one first-order backward with weight gradients (2B sequences); the
+        # interpolates need a first-order backward that keeps adjoints, the tangent pass and the second-order pass, one
+        # after the other (B sequences: launches that cover a sixth to a half of the chip).  The lanes share nothing
+        # but the primal stash (read) and the gradient buffers: the second-order pass, the only other writer, makes
+        # every layer wait for the event the real / fake backward records once that layer's gradients are issued.
+        check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
+                                   ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
+        dh_rf = torch.zeros(Trf, H, dtype=cd, device=dev).index_copy_(0, rgRF.cls_rows, dcls[B:])
+        dhj = torch.zeros(Tj, H, dtype=cd, device=dev).index_copy_(0, rgJ.cls_rows, dcls[:B])
+        m.enable_layer_events()
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dx2 = m._encode_backward(stash, dh_rf, 2 * B, S, param_grads=True, stash_rows=3 * B, row0=B,
+                                     rgd=rg3.desc(B, 2 * B, stash_T=T3), T=Trf)
+        dh_rf.record_stream(side)
+        dx2.record_stream(main)
+        adj = m._new_stash(B, S, Tj, role="adjoint")
+        g = m._encode_backward(stash, dhj, B, S, param_grads=False, adj_stash=adj, stash_rows=3 * B, row0=0, rgd=rgd, T=Tj)
+    elif train_encoder:
         # one first-order backward over the 3B sequences (see _critic_update_one_forward)
         check(lib.pg_head_backward(dt, head.store.master.data_ptr(), hstash[B:].data_ptr(), w.data_ptr(), 2 * B, H,
                                    ghead.data_ptr(), dcls[B:].data_ptr(), H, st), "pg_head_backward")
@@ -480,7 +515,10 @@ def _critic_update_ragged(critic: Critic, critic_optimizer, real, rmask, fake, f
                 grad_sync()
             critic_optimizer.step()
         return c_loss.detach()
-    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0, adj_rows=3 * B, rgd=rgd, T=Tj)
+    xbar = m._encode_backward2(stash, adj, tan, B, S, want_xbar=True, stash_rows=3 * B, row0=0,
+                               adj_rows=0 if two_streams else 3 * B, rgd=rgd, T=Tj, wait_layer_events=two_streams)
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
     # the interpolates' input gradient joins the real and fake rows' own (loss.py:29), then one embedding backward
     check(lib.pg_interpolate_bwd_ragged(dt, xbar.data_ptr(), alpha.data_ptr(), dx2.data_ptr(), dx2.data_ptr(),
                                         rgJ.seq_id.data_ptr(), rgJ.seq_off.data_ptr(), off_r.data_ptr(), off_f.data_ptr(), Tj, H,
