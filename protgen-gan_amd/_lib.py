@@ -52,6 +52,11 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python protgen-gan_amd/build.py` "
         "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+# torch first: its wheel carries a HIP runtime of its own, and the streams and device pointers this library is handed
+# come from that copy.  Opened before torch, the library would bind to the system's runtime instead and every launch
+# on a torch stream would fail.
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
