@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-fill-ahead", action="store_true",
                     help="fill an iteration's fake batches at its start instead of beside the previous iteration's updates "
                          "(train.FillAhead; blind mode with the reference's generator update only)")
+    ap.add_argument("--no-lanes", action="store_true",
+                    help="critic updates on one stream (train.TWO_STREAM_BACKWARD_DEFAULT off): with --no-fill-ahead, every "
+                         "launch has the chip to itself, which is what a kernel trace for per-kernel rates wants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generate-leg", action="store_true", help="skip the generated-sequences/s leg after the train leg")
     ap.add_argument("--generate-batches", type=int, default=3, help="batches of 64 sequences per rank in that leg")
@@ -103,6 +106,8 @@ def main():
     from protgen_gan_amd import train as pgt
     from protgen_gan_amd._lib import lib
 
+    if args.no_lanes:
+        pgt.TWO_STREAM_BACKWARD_DEFAULT = False
     rank, local, world = pgd.init_from_env()
     if torch.distributed.is_initialized():
         # the ranks the process group actually has, not what the environment announced
@@ -232,6 +237,8 @@ def main():
     if ahead is not None:
         ahead.close()
         n_serial = min(args.steps, 4)
+        lanes_were = pgt.TWO_STREAM_BACKWARD_DEFAULT
+        pgt.TWO_STREAM_BACKWARD_DEFAULT = False  # one stream only: a launch's duration is then its own
         one_step(args.warmup, ahead=None)
         fence()
         lib.pg_profile_begin(args.profile_sample)
@@ -244,8 +251,10 @@ def main():
         nl1 = ctypes.c_int64(0)
         lib.pg_profile_end(prof1, ctypes.byref(nl1))
         v1 = variant_table(prof1)
+        pgt.TWO_STREAM_BACKWARD_DEFAULT = lanes_were
         serial = {"steps": n_serial, "ms_per_step": round(dt1 / n_serial * 1e3, 2),
-                  "what": "the same iterations with the fill at their start (no overlap), after the timed region",
+                  "what": "the same iterations on one stream (fill at their start, critic updates without their second lane), "
+                          "after the timed region",
                   "variants": v1, "gemm_launches_total": int(nl1.value)}
     generator.fill_shapes[:], generator.fill_widths[:] = fill_log
     pgt.EXEC_LOG[:] = exec_log
@@ -356,8 +365,9 @@ def main():
                     "max": round(max(step_ms), 2), "each": [round(v, 1) for v in step_ms],
                     "fill_token_rows_each": fill_rows},
         "c_loss": c_loss, "g_loss": g_loss,
-        "schedule": ("next iteration's fill beside this iteration's updates (train.FillAhead)" if ahead is not None
-                     else "fill, then updates"),
+        "schedule": (("next iteration's fill beside this iteration's updates (train.FillAhead)" if ahead is not None
+                      else "fill, then updates")
+                     + ("; critic updates in two lanes" if pgt.TWO_STREAM_BACKWARD_DEFAULT and args.regime == "unfrozen" else "")),
         "one_after_the_other": serial,
         "roofline": roofline, "gemm_variants": variants, "gemm_variants_overlapped": variants_timed,
     }
