@@ -211,6 +211,41 @@ def test_fill_ahead_gives_the_same_iterations_bf16(pg, monkeypatch):
         assert abs(c1 - c0) <= 2e-3 * abs(c0) + 1e-4 and abs(g1 - g0) <= 2e-3 * abs(g0) + 1e-2, (out[False][0], out[True][0])
 
 
+def test_seeded_iterations_with_the_fill_ahead(pg, monkeypatch):
+    """Two seeded-mode iterations (10p_train.py's loop; 2 layers of ProtBERT's width, batch 4 x S 256, n_critic 2) with the
+    next iteration's fakes grown on the side stream: every fake keeps the pads, [CLS] / [SEP] and the unmasked
+    residues of the generator batch it started from and has (next to) no mask left, the losses are finite, and nothing
+    stays in flight after the last iteration."""
+    from protgen_gan_amd import train as T
+    cfg = pg.ProtBertConfig(num_hidden_layers=2)
+    hp = T.GanHyper(n_critic=2, lambda_gp=5.0, max_len=256)
+    gen = pg.Generator(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=0))
+    torch.manual_seed(2)
+    critic = pg.Critic(pg.ProtBertForMaskedLM(cfg, device=DEV, compute_dtype=BF).init_random(seed=1))
+    gopt, copt = pg.AdamW(gen.parameters(), lr=5e-6), pg.AdamW(critic.parameters(), lr=5e-5)
+    rng, tgen = random.Random(9), torch.Generator().manual_seed(9)
+    pool = list(range(100, 251))
+    real = [[T.synthetic_real_batch(4, pool, 256, DEV, rng, tgen) for _ in range(2)] for _ in range(2)]
+    seeds = [[T.synthetic_real_batch(4, pool, 256, DEV, rng, tgen) for _ in range(3)] for _ in range(2)]
+    seen = []
+    orig_cu = T.critic_update
+    monkeypatch.setattr(T, "critic_update", lambda cr, op, rd, am, fd, *a, **k: (seen.append(fd.clone()), orig_cu(cr, op, rd, am, fd, *a, **k))[1])
+    ahead = T.FillAhead(DEV)
+    for i in range(2):
+        c, g = T.gan_step_seeded(gen, critic, gopt, copt, real[i], seeds[i], hp, fill_ahead=ahead,
+                                 next_gen_batches=seeds[i + 1] if i + 1 < 2 else None)
+        assert torch.isfinite(c) and torch.isfinite(g)
+    torch.cuda.synchronize()
+    assert not ahead.pending() and len(seen) == 4
+    starts = [gb["input_ids"] for it in seeds for gb in it[:2]]
+    for fake, x in zip(seen, starts):
+        # every mask was filled; a random-weight generator may itself draw id 4 on the last pass (1 in 30 per site)
+        assert int((fake == 4).sum()) <= 0.02 * fake.numel()
+        special = (x == 0) | (x == 2) | (x == 3)
+        assert torch.equal(fake[special], x[special])           # pads, [CLS], [SEP] where they were
+        assert float((fake == x).float().mean()) > 0.1          # the tenth of the residues that was never masked (and more)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
 def test_micro_batched_critic_update_is_the_same_update(pg, dtype):
     """critic_update(micro_batch=3) on 8 rows (slices of 3, 3 and 2) against the update in one piece: the same loss and
