@@ -19,6 +19,8 @@
 #include "pg_common.h"
 #include "protgen_hip.h"
 
+int pg_internal_attn_resident = 1;  // 0 = the ring kernels at every length (pg_tune key 25)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -764,11 +766,407 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 }
 
 
+// The same pass for sequences of at most RES_KEYS keys: all K and V tiles of the head are staged once and stay in
+// LDS, so the sweep over the keys has no LDS-DMA in flight, no barrier and no drained wait (the ring above waits
+// for its next tile, and with it for the P loads and dS stores around it, once per 64 keys).  A workgroup is
+// 8 waves = 256 query rows, every wave on its own after the one barrier behind the staging; P arrives two tiles
+// ahead of its use.  STORE_DS = false leaves dS unwritten (a caller that contracts the key side from P alone).
+constexpr int RES_NT = 8;              // 64-key tiles that fit: K and V of 512 keys are 128 KiB
+constexpr int RES_KEYS = RES_NT * KT;
+constexpr int RES_QB = 256;            // query rows per workgroup
+
+// Stages tiles [0, nt) of two [rows][64] operands into tile slots of 2 * TILE elements ([A | B] per tile).
+__device__ __forceinline__ void stage_resident(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, long ld, int nt, int rows,
+                                               bf16_t* smem, int wid, int nw, int lane) {
+  const int rl = lane >> 3;
+  const int c = (lane & 7) ^ rl;
+  for (int i = wid; i < nt * 16; i += nw) {
+    const int tile = i >> 4, op = (i >> 3) & 1, pi = i & 7;
+    int rg = tile * KT + 8 * pi + rl;
+    rg = rg < rows ? rg : rows - 1;
+    const bf16_t* src = (op ? Bm : A) + (long)rg * ld + c * 8;
+    __builtin_amdgcn_global_load_lds(src, smem + (tile * 2 + op) * TILE + pi * 512, 16, 0, 0);
+  }
+}
+
+// Per-lane LDS offsets of the resident kernels.  Key order inside a 64-key tile: row m of MFMA block blk is key
+// 32 (blk >> 1) + 8 (m >> 2) + 4 (blk & 1) + (m & 3), so a lane's accumulators of blocks 2j and 2j + 1 are the 8 consecutive
+// keys 32 j + 8 g .. + 7 of its query: score-shaped operands move 16 bytes per lane, 64 contiguous bytes per row and
+// instruction (the 4-keys-per-block order of the ring kernels moves 8 and 32, and is bound by the issue of those pieces).
+struct ResOffsets {
+  unsigned koff[2][2];  // k-major fragment of block (2j + b1), k-step kk: + 4096 j
+  unsigned voff[2][4];  // transposing read of k-slots 8 g + 4 hi + (0..3), head-dim block d: + 4096 s2
+};
+__device__ __forceinline__ ResOffsets res_offsets(int r, int g) {
+  ResOffsets o;
+#pragma unroll
+  for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int row = 8 * (r >> 2) + 4 * b1 + (r & 3);
+      o.koff[b1][kk] = (unsigned)(row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+    }
+  const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int k = 8 * g + qq + 4 * hi;
+      const int c = 2 * d + (pp >> 1);
+      o.voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+    }
+  return o;
+}
+
+// attn_fwd_p_kernel for sequences of at most RES_KEYS keys, K and V resident.  A wave takes its two 16-query groups one
+// after the other and keeps the whole score row of a group in registers (NT tiles x 16 floats per lane): Q K^T and the
+// exponentials are computed once, where the two sweeps of the ring kernel compute both twice; no barrier after the staging.
+// NT = the sequence's tile count rounded up to even (the register array wants a compile-time extent): a tile past the
+// last one is staged like the others (clamped rows), its keys carry the -inf of the padding, its P is not stored.
+template <int NT>
+__device__ __forceinline__ void fwd_p_rows(const bf16_t* __restrict__ Q, bf16_t* __restrict__ Pz, bf16_t* __restrict__ ctx_rows,
+                                           int S, int nt, int store_rows, int ldS, long ld_qkv, long ld_ctx, int q0, int r, int g,
+                                           const ResOffsets& ro, unsigned smem_addr, unsigned mask_addr) {
+#pragma unroll 1
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    if (q0 + qg * 16 >= store_rows) break;  // (groups past the padded rows of a short sequence; no barrier follows)
+    const int qc = q < S ? q : S - 1;
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 v = *reinterpret_cast<const uint4*>(Q + (long)qc * ld_qkv + kk * 32 + 8 * g);
+      qf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    // ---- scores of the whole row, scaled and masked; row max
+    f32x4 s[NT][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned ka = smem_addr + t * 4 * TILE;
+      const unsigned ma = mask_addr + (unsigned)((t * KT + 8 * g) * 4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 mraw[2], kf[2][2];
+        if (j == 0) {
+          mraw[0] = rd128<0>(ma);
+          mraw[1] = rd128<16>(ma);
+        } else {
+          mraw[0] = rd128<128>(ma);
+          mraw[1] = rd128<144>(ma);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          if (j == 0) {
+            kf[0][kk] = rd128<0>(ka + ro.koff[0][kk]);
+            kf[1][kk] = rd128<0>(ka + ro.koff[1][kk]);
+          } else {
+            kf[0][kk] = rd128<4096>(ka + ro.koff[0][kk]);
+            kf[1][kk] = rd128<4096>(ka + ro.koff[1][kk]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1) {
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[b1][0]), qf[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[b1][1]), qf[1], a, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = a[e] * 0.125f + __uint_as_float(mraw[b1][e]);
+            mx = fmaxf(mx, a[e]);
+          }
+          s[t][2 * j + b1] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (a few fragments at a time: the score row already fills half the registers)
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- exponentials, once; row sum
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __expf(s[t][blk][e] - mx);
+          s[t][blk][e] = pe;
+          sum += pe;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv_l = q < S ? 1.0f / sum : 0.f;  // (rows past the sequence: zeros)
+    // ---- P and P V
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned va = smem_addr + t * 4 * TILE + 2 * TILE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x2 vlo[4], vhi[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          if (j == 0) {
+            vlo[d] = rdtr<0>(va + ro.voff[0][d]);
+            vhi[d] = rdtr<0>(va + ro.voff[1][d]);
+          } else {
+            vlo[d] = rdtr<4096>(va + ro.voff[0][d]);
+            vhi[d] = rdtr<4096>(va + ro.voff[1][d]);
+          }
+        }
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = s[t][2 * j + (e >> 2)][e & 3] * inv_l;
+        if (t < nt && q < store_rows) VecIO<bf16_t, 8>::store(Pz + (long)q * ldS + t * KT + j * 32 + 8 * g, pv);
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p8[e] = (__bf16)pv[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const u32x4 vv = (u32x4){vlo[d][0], vlo[d][1], vhi[d][0], vhi[d][1]};
+          o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), p8, o[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (q < S) {
+      bf16_t* dst = ctx_rows + (long)q * ld_ctx + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float v[4] = {o[d][0], o[d][1], o[d][2], o[d][3]};
+        VecIO<bf16_t, 4>::store(dst + d * 16, v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void attn_fwd_p_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ mask,
+                                                                 bf16_t* __restrict__ P, bf16_t* __restrict__ ctx, int S, int ldS,
+                                                                 int heads, long ld_qkv, long ld_ctx, RaggedArgs rg) {
+  __shared__ __align__(16) bf16_t smem[RES_NT * 2 * TILE + 2 * RES_KEYS];  // tile t: [K | V]; then the additive key mask (fp32)
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * RES_QB >= sp.store_rows) return;
+  S = sp.len;
+  const long row0 = sp.row0;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
+  const float* mrow = mask ? mask + row0 : nullptr;
+  const int q0 = qt * RES_QB + wid * 32;
+  const int nt = (S + KT - 1) / KT;
+  const int ntv = (nt + 1) & ~1;
+  stage_resident(Q + H, Q + 2 * H, ld_qkv, ntv, S, smem, wid, 8, lane);
+  {
+    float* ml = reinterpret_cast<float*>(smem + RES_NT * 2 * TILE);
+    for (int k = threadIdx.x; k < ntv * KT; k += 512) {
+      float a = 0.f;
+      if (k >= S) a = -INFINITY;
+      else if (mrow) a = (1.0f - mrow[k]) * -FLT_MAX;
+      ml[k] = a;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const ResOffsets ro = res_offsets(r, g);
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const unsigned mask_addr = smem_addr + RES_NT * 2 * TILE * 2;
+  bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
+  bf16_t* ctx_rows = ctx + row0 * ld_ctx + h * 64;
+#define PG_FWD_P_ROWS(N) \
+  fwd_p_rows<N>(Q, Pz, ctx_rows, S, nt, sp.store_rows, ldS, ld_qkv, ld_ctx, q0, r, g, ro, smem_addr, mask_addr)
+  if (ntv == 8) PG_FWD_P_ROWS(8);
+  else if (ntv == 6) PG_FWD_P_ROWS(6);
+  else if (ntv == 4) PG_FWD_P_ROWS(4);
+  else PG_FWD_P_ROWS(2);
+#undef PG_FWD_P_ROWS
+}
+
+template <bool STORE_DS>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
+                                                                  const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                                  bf16_t* __restrict__ dS, bf16_t* __restrict__ dq, int S, int ldS,
+                                                                  int heads, long ld_qkv, long ld_ctx, long ld_dq, RaggedArgs rg) {
+  __shared__ __align__(16) bf16_t smem[RES_NT * 2 * TILE];  // tile t: [V | K]
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (qt * RES_QB >= sp.store_rows) return;
+  S = sp.len;
+  const long row0 = sp.row0;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* K = qkv + row0 * ld_qkv + h * 64 + H;
+  const bf16_t* V = K + H;
+  const int q0 = qt * RES_QB + wid * 32;
+  const int nt = (S + KT - 1) / KT;
+  stage_resident(V, K, ld_qkv, nt, S, smem, wid, 8, lane);
+
+  bf16x8_t df[2][2];
+  float delta[2];
+  int qrow[2];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    int q = q0 + qg * 16 + r;
+    q = q < S ? q : S - 1;
+    qrow[qg] = q;
+    float acc = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const long o = (row0 + q) * ld_ctx + h * 64 + kk * 32 + 8 * g;
+      uint4 dv = *reinterpret_cast<const uint4*>(dctx + o);
+      uint4 ov = *reinterpret_cast<const uint4*>(ctx + o);
+      df[qg][kk] = __builtin_bit_cast(bf16x8_t, dv);
+      const bf16_t* de = reinterpret_cast<const bf16_t*>(&dv);
+      const bf16_t* oe = reinterpret_cast<const bf16_t*>(&ov);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf16_bits_to_f32(de[e]) * bf16_bits_to_f32(oe[e]);
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    delta[qg] = acc;
+  }
+  const ResOffsets ro = res_offsets(r, g);
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
+  bf16_t* dSz = dS + (long)bh * sp.slot_rows * ldS;
+  const bf16_t* prow[2] = {Pz + (long)qrow[0] * ldS + 8 * g, Pz + (long)qrow[1] * ldS + 8 * g};
+
+  uint4 p0[2][2], p1[2][2], p2[2][2];
+  auto loadp = [&](uint4 (&dst)[2][2], int t) {
+    t = t < nt ? t : nt - 1;  // (past the last tile: a reload that nothing uses)
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dst[qg][j] = *reinterpret_cast<const uint4*>(prow[qg] + t * KT + j * 32);
+  };
+  loadp(p0, 0);
+  loadp(p1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (q0 >= sp.store_rows) return;  // (a wave past the padded rows of a short sequence; no barrier follows)
+
+  f32x4 o[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // one 64-key tile: P of tile t is in `pc`; tile t + 2 starts its way into `pf`, last used by tile t - 1
+  auto tile_step = [&](int t, const uint4 (&pc)[2][2], uint4 (&pf)[2][2]) {
+    loadp(pf, t + 2);
+    const unsigned va = smem_addr + t * 4 * TILE;
+    const unsigned ka = va + 2 * TILE;
+    u32x4 vf[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      vf[0][kk] = rd128<0>(va + ro.koff[0][kk]);
+      vf[1][kk] = rd128<0>(va + ro.koff[1][kk]);
+      vf[2][kk] = rd128<4096>(va + ro.koff[0][kk]);
+      vf[3][kk] = rd128<4096>(va + ro.koff[1][kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 dp[2][4];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][0]), df[qg][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][1]), df[qg][1], a, 0, 0, 0);
+        dp[qg][blk] = a;
+      }
+    u32x2 klo[2][4], khi[2][4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      klo[0][d] = rdtr<0>(ka + ro.voff[0][d]);
+      khi[0][d] = rdtr<0>(ka + ro.voff[1][d]);
+      klo[1][d] = rdtr<4096>(ka + ro.voff[0][d]);
+      khi[1][d] = rdtr<4096>(ka + ro.voff[1][d]);
+    }
+    bf16x8_t sf[2][2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int q = q0 + qg * 16 + r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint4 pr = pc[qg][j];
+        const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w};
+        float ds[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+          float v = pe * (dp[qg][2 * j + (e >> 2)][e & 3] - delta[qg]);
+          if (q >= S) v = 0.f;  // (rows past the sequence: zeros)
+          ds[e] = v;
+          dp[qg][2 * j + (e >> 2)][e & 3] = v;
+        }
+        if (STORE_DS && q < sp.store_rows) VecIO<bf16_t, 8>::store(dSz + (long)q * ldS + t * KT + j * 32 + 8 * g, ds);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t p8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p8[e] = (__bf16)dp[qg][2 * s2][e];
+          p8[4 + e] = (__bf16)dp[qg][2 * s2 + 1][e];
+        }
+        sf[qg][s2] = p8;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32x4 kv = (u32x4){klo[s2][d][0], klo[s2][d][1], khi[s2][d][0], khi[s2][d][1]};
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, kv);
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf[qg][s2], o[qg][d], 0, 0, 0);
+      }
+  };
+  for (int t = 0; t < nt; t += 3) {  // (the three register sets rotate by name: no copies, so every wait stays a counted one)
+    tile_step(t, p0, p2);
+    if (t + 1 < nt) tile_step(t + 1, p1, p0);
+    if (t + 2 < nt) tile_step(t + 2, p2, p1);
+  }
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int q = q0 + qg * 16 + r;
+    if (q >= S) continue;
+    bf16_t* dst = dq + (row0 + q) * ld_dq + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float v[4] = {o[qg][d][0] * 0.125f, o[qg][d][1] * 0.125f, o[qg][d][2] * 0.125f, o[qg][d][3] * 0.125f};
+      VecIO<bf16_t, 4>::store(dst + d * 16, v);
+    }
+  }
+}
+
+
 // ---- gradient-penalty passes over the stored probabilities ---------------------------------
 // Both kernels below keep the query-on-the-lane formulation: a score-shaped product X^T = T R^T
 // takes its A operand from a 64-key LDS tile T (K, dK, V or dV rows, k-major in the head
 // dimension) and its B operand from per-lane row fragments R[q][32kk + 8g .. +8] read once from
-// global memory; lane (q = lane & 15, g = lane >> 4) then holds keys 16 blk + 4g + e of query q.
+// global memory; lane (q = lane & 15, g = lane >> 4) then holds, in blocks 2j and 2j + 1, the 8 consecutive keys
+// 32 j + 8 g .. + 7 of query q (the key order of res_offsets).
 
 // Row fragments of one [T][ld] activation (head h): both 16-query groups, both k-steps.
 __device__ __forceinline__ void load_row_frags(const bf16_t* __restrict__ base, long ld, const int (&qrow)[2], int g,
@@ -797,13 +1195,13 @@ __device__ __forceinline__ void row_dots(const bf16x8_t (&a)[2][2], const bf16x8
   }
 }
 
-__device__ __forceinline__ void read_kmajor_frags(unsigned tile_addr, const unsigned (&koff)[2], u32x4 (&f)[4][2]) {
+__device__ __forceinline__ void read_kmajor_frags(unsigned tile_addr, const unsigned (&koff)[2][2], u32x4 (&f)[4][2]) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    f[0][kk] = rd128<0>(tile_addr + koff[kk]);
-    f[1][kk] = rd128<2048>(tile_addr + koff[kk]);
-    f[2][kk] = rd128<4096>(tile_addr + koff[kk]);
-    f[3][kk] = rd128<6144>(tile_addr + koff[kk]);
+    f[0][kk] = rd128<0>(tile_addr + koff[0][kk]);
+    f[1][kk] = rd128<0>(tile_addr + koff[1][kk]);
+    f[2][kk] = rd128<4096>(tile_addr + koff[0][kk]);
+    f[3][kk] = rd128<4096>(tile_addr + koff[1][kk]);
   }
 }
 
@@ -866,21 +1264,7 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
   load_row_frags(Q, ld_qkv, qrow, g, qf);
   load_row_frags(Qd, ld_qkv, qrow, g, qdf);
 
-  unsigned koff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
-  unsigned voff[2][4];
-  {
-    const int qq = r >> 2, pp = r & 3;
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int k = 4 * g + qq + 16 * hi;
-        const int c = 2 * d + (pp >> 1);
-        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
-      }
-  }
+  const ResOffsets ro = res_offsets(r, g);
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
   const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
@@ -892,12 +1276,11 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint2 pcur[2][4], pnext[2][4];
+  uint4 pcur[2][2], pnext[2][2];
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+    for (int j = 0; j < 2; ++j) pcur[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + j * 32 + 8 * g);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_tile(Q + H, ld_qkv, 0, S, smem, wid, lane);
   stage_tile(Qd + H, ld_qkv, 0, S, smem + TILE, wid, lane);
@@ -909,8 +1292,8 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
-          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+        for (int j = 0; j < 2; ++j)
+          pnext[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + j * 32 + 8 * g);
       bf16_t* nb = smem + ((t + 1) & 1) * 4 * TILE;
       stage_tile(Q + H, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
       stage_tile(Qd + H, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
@@ -922,12 +1305,12 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
     f32x4 ds[2][4];
     {
       u32x4 kf[4][2];
-      read_kmajor_frags(ka, koff, kf);
+      read_kmajor_frags(ka, ro.koff, kf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product<true>(kf, qdf, ds);
       __builtin_amdgcn_sched_barrier(0);
-      read_kmajor_frags(kda, koff, kf);
+      read_kmajor_frags(kda, ro.koff, kf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product<false>(kf, qf, ds);
@@ -937,25 +1320,24 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
     u32x2 vlo[2][4], vhi[2][4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      vlo[0][d] = rdtr<0>(va + voff[0][d]);
-      vhi[0][d] = rdtr<0>(va + voff[1][d]);
-      vlo[1][d] = rdtr<4096>(va + voff[0][d]);
-      vhi[1][d] = rdtr<4096>(va + voff[1][d]);
+      vlo[0][d] = rdtr<0>(va + ro.voff[0][d]);
+      vhi[0][d] = rdtr<0>(va + ro.voff[1][d]);
+      vlo[1][d] = rdtr<4096>(va + ro.voff[0][d]);
+      vhi[1][d] = rdtr<4096>(va + ro.voff[1][d]);
     }
     bf16x8_t pdf[2][2], pf[2][2];
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const uint2 pr = pcur[qg][blk];
-        const float p0 = __uint_as_float(pr.x << 16), p1 = __uint_as_float(pr.x & 0xffff0000u);
-        const float p2 = __uint_as_float(pr.y << 16), p3 = __uint_as_float(pr.y & 0xffff0000u);
-        const float pd[4] = {p0 * ds[qg][blk][0] * 0.125f, p1 * ds[qg][blk][1] * 0.125f, p2 * ds[qg][blk][2] * 0.125f,
-                             p3 * ds[qg][blk][3] * 0.125f};
+      for (int j = 0; j < 2; ++j) {
+        const uint4 pr = pcur[qg][j];
+        const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          racc[qg] += pd[e];
-          ds[qg][blk][e] = pd[e];
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+          const float pd = pe * ds[qg][2 * j + (e >> 2)][e & 3] * 0.125f;
+          racc[qg] += pd;
+          ds[qg][2 * j + (e >> 2)][e & 3] = pd;
         }
       }
 #pragma unroll
@@ -967,7 +1349,7 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
           p8[4 + e] = (__bf16)ds[qg][2 * s2 + 1][e];
         }
         pdf[qg][s2] = p8;
-        const u32x4 raw = (u32x4){pcur[qg][2 * s2].x, pcur[qg][2 * s2].y, pcur[qg][2 * s2 + 1].x, pcur[qg][2 * s2 + 1].y};
+        const u32x4 raw = (u32x4){pcur[qg][s2].x, pcur[qg][s2].y, pcur[qg][s2].z, pcur[qg][s2].w};
         pf[qg][s2] = __builtin_bit_cast(bf16x8_t, raw);
       }
     }
@@ -985,10 +1367,10 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {  // dV^T into the same registers
-      vlo[0][d] = rdtr<0>(vda + voff[0][d]);
-      vhi[0][d] = rdtr<0>(vda + voff[1][d]);
-      vlo[1][d] = rdtr<4096>(vda + voff[0][d]);
-      vhi[1][d] = rdtr<4096>(vda + voff[1][d]);
+      vlo[0][d] = rdtr<0>(vda + ro.voff[0][d]);
+      vhi[0][d] = rdtr<0>(vda + ro.voff[1][d]);
+      vlo[1][d] = rdtr<4096>(vda + ro.voff[0][d]);
+      vhi[1][d] = rdtr<4096>(vda + ro.voff[1][d]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -1005,7 +1387,7 @@ __global__ __launch_bounds__(256, 2) void attn_jvp_kernel(const bf16_t* __restri
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+      for (int j = 0; j < 2; ++j) pcur[qg][j] = pnext[qg][j];
     __syncthreads();
   }
 #pragma unroll
@@ -1082,21 +1464,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
     }
   }
 
-  unsigned koff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+  const ResOffsets ro = res_offsets(r, g);
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
   const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
   bf16_t* Sbz = Sbar + (long)bh * sp.slot_rows * ldS;
   bf16_t* Pdz = Pdot + (long)bh * sp.slot_rows * ldS;
 
-  uint2 pcur[2][4], pnext[2][4];
+  uint4 pcur[2][2], pnext[2][2];
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+    for (int j = 0; j < 2; ++j) pcur[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + j * 32 + 8 * g);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_tile(Q + H, ld_qkv, 0, S, smem, wid, lane);
   stage_tile(Qd + H, ld_qkv, 0, S, smem + TILE, wid, lane);
@@ -1108,8 +1487,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
-          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+        for (int j = 0; j < 2; ++j)
+          pnext[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + j * 32 + 8 * g);
       bf16_t* nb = smem + ((t + 1) & 1) * 4 * TILE;
       stage_tile(Q + H, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
       stage_tile(Qd + H, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
@@ -1124,45 +1503,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
     for (int qg = 0; qg < 2; ++qg) {
       f32x4 ds[4], gm[4], xx[4];
       u32x4 tf[4][2];
-      read_kmajor_frags(ka, koff, tf);
+      read_kmajor_frags(ka, ro.koff, tf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product1<true>(tf, qdf[qg], ds);
       __builtin_amdgcn_sched_barrier(0);
-      read_kmajor_frags(kda, koff, tf);
+      read_kmajor_frags(kda, ro.koff, tf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product1<false>(tf, qf[qg], ds);
       __builtin_amdgcn_sched_barrier(0);
-      read_kmajor_frags(va, koff, tf);
+      read_kmajor_frags(va, ro.koff, tf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product1<true>(tf, gf[qg], gm);
       score_product1<true>(tf, cbf[qg], xx);
       __builtin_amdgcn_sched_barrier(0);
-      read_kmajor_frags(vda, koff, tf);
+      read_kmajor_frags(vda, ro.koff, tf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       score_product1<false>(tf, gf[qg], xx);
       __builtin_amdgcn_sched_barrier(0);
       const int q = q0 + qg * 16 + r;
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const uint2 pr = pcur[qg][blk];
-        const float pv[4] = {__uint_as_float(pr.x << 16), __uint_as_float(pr.x & 0xffff0000u), __uint_as_float(pr.y << 16),
-                             __uint_as_float(pr.y & 0xffff0000u)};
-        float sb[4], pd[4];
+      for (int j = 0; j < 2; ++j) {
+        const uint4 pr = pcur[qg][j];
+        const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w};
+        float sb[8], pd[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = ds[blk][e] * 0.125f;
-          const float pbar = xx[blk][e] + gm[blk][e] * (d - rq[qg]) - cq[qg] * d;
-          sb[e] = q < S ? pv[e] * (pbar - eq[qg]) : 0.f;  // (rows past the sequence: zeros)
-          pd[e] = q < S ? pv[e] * (d - rq[qg]) : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          const int blk = 2 * j + (e >> 2), ee = e & 3;
+          const float pv = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+          const float d = ds[blk][ee] * 0.125f;
+          const float pbar = xx[blk][ee] + gm[blk][ee] * (d - rq[qg]) - cq[qg] * d;
+          sb[e] = q < S ? pv * (pbar - eq[qg]) : 0.f;  // (rows past the sequence: zeros)
+          pd[e] = q < S ? pv * (d - rq[qg]) : 0.f;
         }
         if (q < sp.store_rows) {
-          const long o = (long)q * ldS + t * KT + blk * 16 + 4 * g;
-          VecIO<bf16_t, 4>::store(Sbz + o, sb);
-          VecIO<bf16_t, 4>::store(Pdz + o, pd);
+          const long o = (long)q * ldS + t * KT + j * 32 + 8 * g;
+          VecIO<bf16_t, 8>::store(Sbz + o, sb);
+          VecIO<bf16_t, 8>::store(Pdz + o, pd);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1170,7 +1550,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const bf16_t* __restr
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+      for (int j = 0; j < 2; ++j) pcur[qg][j] = pnext[qg][j];
     __syncthreads();
   }
 }
@@ -1225,6 +1605,12 @@ int launch_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* c
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)P) & 7)) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  if (pg_internal_attn_resident && S <= RES_KEYS && !(((uintptr_t)P) & 15)) {
+    const dim3 grid(((seq_off ? h.ldS : S) + RES_QB - 1) / RES_QB, n * heads);
+    hipLaunchKernelGGL(attn_fwd_p_res_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
+                       (bf16_t*)ctx, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, h.rg);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(attn_fwd_p_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
                      (bf16_t*)ctx, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
@@ -1239,6 +1625,13 @@ int launch_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, co
   if ((((uintptr_t)qkv) | ((uintptr_t)ctx) | ((uintptr_t)dctx)) & 15) return PG_ERR_ALIGN;
   if ((((uintptr_t)P) | ((uintptr_t)dS) | ((uintptr_t)dq)) & 7) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  if (pg_internal_attn_resident && S <= RES_KEYS && !((((uintptr_t)P) | ((uintptr_t)dS)) & 15)) {
+    const dim3 grid(((seq_off ? h.ldS : S) + RES_QB - 1) / RES_QB, n * heads);
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
+                       (long)ld_ctx, (long)ld_dq, h.rg);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
                      (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
                      (long)ld_ctx, (long)ld_dq, h.rg);
@@ -1252,7 +1645,8 @@ int launch_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, cons
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 4) || (ld_out % 4)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)tqkv)) & 15) return PG_ERR_ALIGN;
-  if ((((uintptr_t)P) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot)) & 7) return PG_ERR_ALIGN;
+  if ((((uintptr_t)ctx) | ((uintptr_t)ctxdot)) & 7) return PG_ERR_ALIGN;
+  if (((uintptr_t)P) & 15) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
   hipLaunchKernelGGL(attn_jvp_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
                      (const bf16_t*)P, (const bf16_t*)ctx, (bf16_t*)ctxdot, rho, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx,
@@ -1269,7 +1663,7 @@ int launch_bwd2(int dtype, const void* qkv, const void* tqkv, const void* P, con
   if ((ld_qkv % 8) || (ld_ctx % 8)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)tqkv) | ((uintptr_t)ctx) | ((uintptr_t)ctxdot) | ((uintptr_t)gctx) | ((uintptr_t)ctxbar)) & 15)
     return PG_ERR_ALIGN;
-  if ((((uintptr_t)P) | ((uintptr_t)Sbar) | ((uintptr_t)Pdot)) & 7) return PG_ERR_ALIGN;
+  if ((((uintptr_t)P) | ((uintptr_t)Sbar) | ((uintptr_t)Pdot)) & 15) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
   hipLaunchKernelGGL(attn_bwd2_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)tqkv,
                      (const bf16_t*)P, (const bf16_t*)ctx, (const bf16_t*)ctxdot, (const bf16_t*)gctx, (const bf16_t*)ctxbar, rho,

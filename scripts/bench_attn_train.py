@@ -84,3 +84,21 @@ for name, d in (("3B = 24 sequences", full), ("B = 8 sequences", part)):
         us = timeit(fn, NSETS)
         print(f"  {k:7s} {us:7.1f} us   score-shaped traffic {nbuf * score_bytes / us / 1e6:5.2f} TB/s   "
               f"{nprod * fl_unit / us / 1e6:5.0f} TFLOP/s ({nprod} products)", flush=True)
+
+# the inference forward of the fill loop: 68 sequences, all keys visible / half of them (walk over the visible-key list)
+lens68 = [(rng.randint(200, 500) + 2 + 7) // 8 * 8 for _ in range(68)]
+rg68 = Ragged(lens68, S, DEV)
+T68 = rg68.T
+qkv68 = (torch.randn(T68, 3 * H, device=DEV, generator=g)).to(BF)
+ctx68 = torch.empty(T68, H, dtype=BF, device=DEV)
+fl68 = sum(L * L for L in lens68) * heads * 64 * 2 * 2
+for name, frac in (("all keys", 1.0), ("half the keys", 0.5)):
+    m = (torch.rand(T68, device=DEV, generator=g) < frac).float() if frac < 1 else torch.ones(T68, device=DEV)
+    idx = torch.empty(T68, dtype=torch.int32, device=DEV)
+    cnt = torch.empty(68, dtype=torch.int32, device=DEV)
+    assert lib.pg_attention_key_lists(m.data_ptr(), rg68.seq_off.data_ptr(), 68, S, idx.data_ptr(), cnt.data_ptr(), st) == 0
+    fn = lambda i: lib.pg_attention_fwd_keys(1, qkv68.data_ptr(), m.data_ptr(), ctx68.data_ptr(), rg68.seq_off.data_ptr(), 68, S,  # noqa: E731
+                                             heads, 3 * H, H, idx.data_ptr(), cnt.data_ptr(), st)
+    assert fn(0) == 0
+    us = timeit(fn, 4)
+    print(f"inference forward, 68 sequences, {name}: {us:7.1f} us   {fl68 * frac / us / 1e6:5.0f} TFLOP/s", flush=True)
