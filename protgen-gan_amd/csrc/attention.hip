@@ -19,7 +19,7 @@
 #include "pg_common.h"
 #include "protgen_hip.h"
 
-int pg_internal_attn_resident = 1;  // 0 = the ring kernels at every length (pg_tune key 25)
+int pg_internal_attn_resident = 1;  // 0 = the forward that writes P streams K / V through the ring at every length (pg_tune key 25)
 
 namespace {
 
@@ -365,6 +365,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// Per-lane LDS offsets of the kernels that read or write score-shaped operands.  Key order inside a 64-key tile: row m of MFMA block blk is key
+// 32 (blk >> 1) + 8 (m >> 2) + 4 (blk & 1) + (m & 3), so a lane's accumulators of blocks 2j and 2j + 1 are the 8 consecutive
+// keys 32 j + 8 g .. + 7 of its query: score-shaped operands move 16 bytes per lane, 64 contiguous bytes per row and
+// instruction (keys 16 blk + 4 g .. + 3, the order of the inference forward, would move 8 and 32, and the issue of those
+// pieces is what bounds these kernels).
+struct ResOffsets {
+  unsigned koff[2][2];  // k-major fragment of block (2j + b1), k-step kk: + 4096 j
+  unsigned voff[2][4];  // transposing read of k-slots 8 g + 4 hi + (0..3), head-dim block d: + 4096 s2
+};
+__device__ __forceinline__ ResOffsets res_offsets(int r, int g) {
+  ResOffsets o;
+#pragma unroll
+  for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int row = 8 * (r >> 2) + 4 * b1 + (r & 3);
+      o.koff[b1][kk] = (unsigned)(row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+    }
+  const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int k = 8 * g + qq + 4 * hi;
+      const int c = 2 * d + (pp >> 1);
+      o.voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
+    }
+  return o;
+}
+
 // Training-pass variant: the same products, but the normalised probabilities P (bf16,
 // [B*heads][S][ldS], zeros in the padding columns) are written once for the backward and the
 // gradient-penalty passes.  Two sweeps over the keys: the first computes each query row's
@@ -414,21 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  unsigned koff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
-  unsigned voff[2][4];
-  {
-    const int qq = r >> 2, pp = r & 3;
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int k = 4 * g + qq + 16 * hi;
-        const int c = 2 * d + (pp >> 1);
-        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
-      }
-  }
+  const ResOffsets ro = res_offsets(r, g);
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const unsigned mask_addr = smem_addr + 4 * TILE * 2;
   const int nt = (S + KT - 1) / KT;
@@ -436,18 +452,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
   // scores of one key tile for both query groups, scaled and masked
   auto scores = [&](unsigned ka, int t, f32x4 (&s)[2][4]) {
     u32x4 mraw[4];
-    const unsigned ma = mask_addr + (unsigned)((t * KT + 4 * g) * 4);
+    const unsigned ma = mask_addr + (unsigned)((t * KT + 8 * g) * 4);
     mraw[0] = rd128<0>(ma);
-    mraw[1] = rd128<64>(ma);
+    mraw[1] = rd128<16>(ma);
     mraw[2] = rd128<128>(ma);
-    mraw[3] = rd128<192>(ma);
+    mraw[3] = rd128<144>(ma);
     u32x4 kf[4][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      kf[0][kk] = rd128<0>(ka + koff[kk]);
-      kf[1][kk] = rd128<2048>(ka + koff[kk]);
-      kf[2][kk] = rd128<4096>(ka + koff[kk]);
-      kf[3][kk] = rd128<6144>(ka + koff[kk]);
+      kf[0][kk] = rd128<0>(ka + ro.koff[0][kk]);
+      kf[1][kk] = rd128<0>(ka + ro.koff[1][kk]);
+      kf[2][kk] = rd128<4096>(ka + ro.koff[0][kk]);
+      kf[3][kk] = rd128<4096>(ka + ro.koff[1][kk]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -519,24 +535,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
     u32x2 vlo[2][4], vhi[2][4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      vlo[0][d] = rdtr<0>(va + voff[0][d]);
-      vhi[0][d] = rdtr<0>(va + voff[1][d]);
-      vlo[1][d] = rdtr<4096>(va + voff[0][d]);
-      vhi[1][d] = rdtr<4096>(va + voff[1][d]);
+      vlo[0][d] = rdtr<0>(va + ro.voff[0][d]);
+      vhi[0][d] = rdtr<0>(va + ro.voff[1][d]);
+      vlo[1][d] = rdtr<4096>(va + ro.voff[0][d]);
+      vhi[1][d] = rdtr<4096>(va + ro.voff[1][d]);
     }
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
       const int q = q0 + qg * 16 + r;
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        float pv[4];
+      for (int j = 0; j < 2; ++j) {
+        float pv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pv[e] = q < S ? __expf(s[qg][blk][e] - m_run[qg]) * inv_l[qg] : 0.f;  // (rows past the sequence: zeros)
-          s[qg][blk][e] = pv[e];
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = q < S ? __expf(s[qg][2 * j + (e >> 2)][e & 3] - m_run[qg]) * inv_l[qg] : 0.f;  // (rows past the sequence: zeros)
+          s[qg][2 * j + (e >> 2)][e & 3] = pv[e];
         }
-        if (q < sp.store_rows) VecIO<bf16_t, 4>::store(Pz + (long)q * ldS + t * KT + blk * 16 + 4 * g, pv);
+        if (q < sp.store_rows) VecIO<bf16_t, 8>::store(Pz + (long)q * ldS + t * KT + j * 32 + 8 * g, pv);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -627,21 +643,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     delta[qg] = acc;
   }
 
-  unsigned koff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) koff[kk] = (unsigned)(r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
-  unsigned voff[2][4];
-  {
-    const int qq = r >> 2, pp = r & 3;
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int k = 4 * g + qq + 16 * hi;
-        const int c = 2 * d + (pp >> 1);
-        voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
-      }
-  }
+  const ResOffsets ro = res_offsets(r, g);
   const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
   const int nt = (S + KT - 1) / KT;
   const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
@@ -655,12 +657,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 
   // P of the current tile is fetched one iteration ahead, before that iteration's LDS-DMA is
   // issued, so its wait never drains the DMA ring.
-  uint2 pcur[2][4], pnext[2][4];
+  uint4 pcur[2][2], pnext[2][2];
 #pragma unroll
   for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-      pcur[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + blk * 16 + 4 * g);
+    for (int j = 0; j < 2; ++j) pcur[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + j * 32 + 8 * g);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_tile(V, ld_qkv, 0, S, smem, wid, lane);          // slot 0: V (k-major in d for dP^T = V dO^T)
   stage_tile(K, ld_qkv, 0, S, smem + TILE, wid, lane);   // slot 1: K (transposed reads for dQ^T = K^T dS^T)
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
-          pnext[qg][blk] = *reinterpret_cast<const uint2*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + blk * 16 + 4 * g);
+        for (int j = 0; j < 2; ++j)
+          pnext[qg][j] = *reinterpret_cast<const uint4*>(Pz + (long)qrow[qg] * ldS + (t + 1) * KT + j * 32 + 8 * g);
       bf16_t* nb = smem + ((t + 1) & 1) * 2 * TILE;
       stage_tile(V, ld_qkv, (t + 1) * KT, S, nb, wid, lane);
       stage_tile(K, ld_qkv, (t + 1) * KT, S, nb + TILE, wid, lane);
@@ -681,10 +682,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     u32x4 vf[4][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      vf[0][kk] = rd128<0>(va + koff[kk]);
-      vf[1][kk] = rd128<2048>(va + koff[kk]);
-      vf[2][kk] = rd128<4096>(va + koff[kk]);
-      vf[3][kk] = rd128<6144>(va + koff[kk]);
+      vf[0][kk] = rd128<0>(va + ro.koff[0][kk]);
+      vf[1][kk] = rd128<0>(va + ro.koff[1][kk]);
+      vf[2][kk] = rd128<4096>(va + ro.koff[0][kk]);
+      vf[3][kk] = rd128<4096>(va + ro.koff[1][kk]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -701,28 +702,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     u32x2 klo[2][4], khi[2][4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      klo[0][d] = rdtr<0>(ka + voff[0][d]);
-      khi[0][d] = rdtr<0>(ka + voff[1][d]);
-      klo[1][d] = rdtr<4096>(ka + voff[0][d]);
-      khi[1][d] = rdtr<4096>(ka + voff[1][d]);
+      klo[0][d] = rdtr<0>(ka + ro.voff[0][d]);
+      khi[0][d] = rdtr<0>(ka + ro.voff[1][d]);
+      klo[1][d] = rdtr<4096>(ka + ro.voff[0][d]);
+      khi[1][d] = rdtr<4096>(ka + ro.voff[1][d]);
     }
     bf16x8_t sf[2][2];
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
       const int q = q0 + qg * 16 + r;
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const uint2 pr = pcur[qg][blk];
-        const float p0 = __uint_as_float(pr.x << 16), p1 = __uint_as_float(pr.x & 0xffff0000u);
-        const float p2 = __uint_as_float(pr.y << 16), p3 = __uint_as_float(pr.y & 0xffff0000u);
-        float ds[4] = {p0 * (dp[qg][blk][0] - delta[qg]), p1 * (dp[qg][blk][1] - delta[qg]),
-                       p2 * (dp[qg][blk][2] - delta[qg]), p3 * (dp[qg][blk][3] - delta[qg])};
+      for (int j = 0; j < 2; ++j) {
+        const uint4 pr = pcur[qg][j];
+        const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w};
+        float ds[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (q >= S) ds[e] = 0.f;  // (rows past the sequence: zeros)
-          dp[qg][blk][e] = ds[e];
+        for (int e = 0; e < 8; ++e) {
+          const float pe = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+          float v = pe * (dp[qg][2 * j + (e >> 2)][e & 3] - delta[qg]);
+          if (q >= S) v = 0.f;  // (rows past the sequence: zeros)
+          ds[e] = v;
+          dp[qg][2 * j + (e >> 2)][e & 3] = v;
         }
-        if (q < sp.store_rows) VecIO<bf16_t, 4>::store(dSz + (long)q * ldS + t * KT + blk * 16 + 4 * g, ds);
+        if (q < sp.store_rows) VecIO<bf16_t, 8>::store(dSz + (long)q * ldS + t * KT + j * 32 + 8 * g, ds);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) pcur[qg][blk] = pnext[qg][blk];
+      for (int j = 0; j < 2; ++j) pcur[qg][j] = pnext[qg][j];
     __syncthreads();
   }
 #pragma unroll
@@ -766,11 +768,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 }
 
 
-// The same pass for sequences of at most RES_KEYS keys: all K and V tiles of the head are staged once and stay in
-// LDS, so the sweep over the keys has no LDS-DMA in flight, no barrier and no drained wait (the ring above waits
-// for its next tile, and with it for the P loads and dS stores around it, once per 64 keys).  A workgroup is
-// 8 waves = 256 query rows, every wave on its own after the one barrier behind the staging; P arrives two tiles
-// ahead of its use.  STORE_DS = false leaves dS unwritten (a caller that contracts the key side from P alone).
+// Kernels for sequences of at most RES_KEYS keys keep all K and V tiles of the head in LDS: staged once, then no LDS-DMA in
+// flight, no barrier and no drained wait while the keys are swept.  A workgroup is 8 waves = 256 query rows, every wave
+// on its own after the one barrier behind the staging.
 constexpr int RES_NT = 8;              // 64-key tiles that fit: K and V of 512 keys are 128 KiB
 constexpr int RES_KEYS = RES_NT * KT;
 constexpr int RES_QB = 256;            // query rows per workgroup
@@ -787,35 +787,6 @@ __device__ __forceinline__ void stage_resident(const bf16_t* __restrict__ A, con
     const bf16_t* src = (op ? Bm : A) + (long)rg * ld + c * 8;
     __builtin_amdgcn_global_load_lds(src, smem + (tile * 2 + op) * TILE + pi * 512, 16, 0, 0);
   }
-}
-
-// Per-lane LDS offsets of the resident kernels.  Key order inside a 64-key tile: row m of MFMA block blk is key
-// 32 (blk >> 1) + 8 (m >> 2) + 4 (blk & 1) + (m & 3), so a lane's accumulators of blocks 2j and 2j + 1 are the 8 consecutive
-// keys 32 j + 8 g .. + 7 of its query: score-shaped operands move 16 bytes per lane, 64 contiguous bytes per row and
-// instruction (the 4-keys-per-block order of the ring kernels moves 8 and 32, and is bound by the issue of those pieces).
-struct ResOffsets {
-  unsigned koff[2][2];  // k-major fragment of block (2j + b1), k-step kk: + 4096 j
-  unsigned voff[2][4];  // transposing read of k-slots 8 g + 4 hi + (0..3), head-dim block d: + 4096 s2
-};
-__device__ __forceinline__ ResOffsets res_offsets(int r, int g) {
-  ResOffsets o;
-#pragma unroll
-  for (int b1 = 0; b1 < 2; ++b1)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int row = 8 * (r >> 2) + 4 * b1 + (r & 3);
-      o.koff[b1][kk] = (unsigned)(row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
-    }
-  const int qq = r >> 2, pp = r & 3;
-#pragma unroll
-  for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int k = 8 * g + qq + 4 * hi;
-      const int c = 2 * d + (pp >> 1);
-      o.voff[hi][d] = (unsigned)(k * 128 + ((c ^ (k & 7)) << 4) + 8 * (pp & 1));
-    }
-  return o;
 }
 
 // attn_fwd_p_kernel for sequences of at most RES_KEYS keys, K and V resident.  A wave takes its two 16-query groups one
@@ -992,172 +963,6 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_p_res_kernel(const bf16_t* __
   else if (ntv == 4) PG_FWD_P_ROWS(4);
   else PG_FWD_P_ROWS(2);
 #undef PG_FWD_P_ROWS
-}
-
-template <bool STORE_DS>
-__global__ __launch_bounds__(512, 1) void attn_bwd_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
-                                                                  const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
-                                                                  bf16_t* __restrict__ dS, bf16_t* __restrict__ dq, int S, int ldS,
-                                                                  int heads, long ld_qkv, long ld_ctx, long ld_dq, RaggedArgs rg) {
-  __shared__ __align__(16) bf16_t smem[RES_NT * 2 * TILE];  // tile t: [V | K]
-  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-  const int bh = lid / gridDim.x, qt = lid % gridDim.x;
-  const int b = bh / heads, h = bh % heads;
-  const SeqSpan sp = seq_span(rg, b, S);
-  if (qt * RES_QB >= sp.store_rows) return;
-  S = sp.len;
-  const long row0 = sp.row0;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int H = heads * 64;
-  const bf16_t* K = qkv + row0 * ld_qkv + h * 64 + H;
-  const bf16_t* V = K + H;
-  const int q0 = qt * RES_QB + wid * 32;
-  const int nt = (S + KT - 1) / KT;
-  stage_resident(V, K, ld_qkv, nt, S, smem, wid, 8, lane);
-
-  bf16x8_t df[2][2];
-  float delta[2];
-  int qrow[2];
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
-    int q = q0 + qg * 16 + r;
-    q = q < S ? q : S - 1;
-    qrow[qg] = q;
-    float acc = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const long o = (row0 + q) * ld_ctx + h * 64 + kk * 32 + 8 * g;
-      uint4 dv = *reinterpret_cast<const uint4*>(dctx + o);
-      uint4 ov = *reinterpret_cast<const uint4*>(ctx + o);
-      df[qg][kk] = __builtin_bit_cast(bf16x8_t, dv);
-      const bf16_t* de = reinterpret_cast<const bf16_t*>(&dv);
-      const bf16_t* oe = reinterpret_cast<const bf16_t*>(&ov);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += bf16_bits_to_f32(de[e]) * bf16_bits_to_f32(oe[e]);
-    }
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    delta[qg] = acc;
-  }
-  const ResOffsets ro = res_offsets(r, g);
-  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS;
-  bf16_t* dSz = dS + (long)bh * sp.slot_rows * ldS;
-  const bf16_t* prow[2] = {Pz + (long)qrow[0] * ldS + 8 * g, Pz + (long)qrow[1] * ldS + 8 * g};
-
-  uint4 p0[2][2], p1[2][2], p2[2][2];
-  auto loadp = [&](uint4 (&dst)[2][2], int t) {
-    t = t < nt ? t : nt - 1;  // (past the last tile: a reload that nothing uses)
-#pragma unroll
-    for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dst[qg][j] = *reinterpret_cast<const uint4*>(prow[qg] + t * KT + j * 32);
-  };
-  loadp(p0, 0);
-  loadp(p1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (q0 >= sp.store_rows) return;  // (a wave past the padded rows of a short sequence; no barrier follows)
-
-  f32x4 o[2][4];
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) o[qg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // one 64-key tile: P of tile t is in `pc`; tile t + 2 starts its way into `pf`, last used by tile t - 1
-  auto tile_step = [&](int t, const uint4 (&pc)[2][2], uint4 (&pf)[2][2]) {
-    loadp(pf, t + 2);
-    const unsigned va = smem_addr + t * 4 * TILE;
-    const unsigned ka = va + 2 * TILE;
-    u32x4 vf[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      vf[0][kk] = rd128<0>(va + ro.koff[0][kk]);
-      vf[1][kk] = rd128<0>(va + ro.koff[1][kk]);
-      vf[2][kk] = rd128<4096>(va + ro.koff[0][kk]);
-      vf[3][kk] = rd128<4096>(va + ro.koff[1][kk]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 dp[2][4];
-#pragma unroll
-    for (int qg = 0; qg < 2; ++qg)
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][0]), df[qg][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf[blk][1]), df[qg][1], a, 0, 0, 0);
-        dp[qg][blk] = a;
-      }
-    u32x2 klo[2][4], khi[2][4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      klo[0][d] = rdtr<0>(ka + ro.voff[0][d]);
-      khi[0][d] = rdtr<0>(ka + ro.voff[1][d]);
-      klo[1][d] = rdtr<4096>(ka + ro.voff[0][d]);
-      khi[1][d] = rdtr<4096>(ka + ro.voff[1][d]);
-    }
-    bf16x8_t sf[2][2];
-#pragma unroll
-    for (int qg = 0; qg < 2; ++qg) {
-      const int q = q0 + qg * 16 + r;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint4 pr = pc[qg][j];
-        const unsigned pw[4] = {pr.x, pr.y, pr.z, pr.w};
-        float ds[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pe = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
-          float v = pe * (dp[qg][2 * j + (e >> 2)][e & 3] - delta[qg]);
-          if (q >= S) v = 0.f;  // (rows past the sequence: zeros)
-          ds[e] = v;
-          dp[qg][2 * j + (e >> 2)][e & 3] = v;
-        }
-        if (STORE_DS && q < sp.store_rows) VecIO<bf16_t, 8>::store(dSz + (long)q * ldS + t * KT + j * 32 + 8 * g, ds);
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8_t p8;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          p8[e] = (__bf16)dp[qg][2 * s2][e];
-          p8[4 + e] = (__bf16)dp[qg][2 * s2 + 1][e];
-        }
-        sf[qg][s2] = p8;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const u32x4 kv = (u32x4){klo[s2][d][0], klo[s2][d][1], khi[s2][d][0], khi[s2][d][1]};
-        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, kv);
-#pragma unroll
-        for (int qg = 0; qg < 2; ++qg) o[qg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, sf[qg][s2], o[qg][d], 0, 0, 0);
-      }
-  };
-  for (int t = 0; t < nt; t += 3) {  // (the three register sets rotate by name: no copies, so every wait stays a counted one)
-    tile_step(t, p0, p2);
-    if (t + 1 < nt) tile_step(t + 1, p1, p0);
-    if (t + 2 < nt) tile_step(t + 2, p2, p1);
-  }
-#pragma unroll
-  for (int qg = 0; qg < 2; ++qg) {
-    const int q = q0 + qg * 16 + r;
-    if (q >= S) continue;
-    bf16_t* dst = dq + (row0 + q) * ld_dq + h * 64 + 4 * g;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      float v[4] = {o[qg][d][0] * 0.125f, o[qg][d][1] * 0.125f, o[qg][d][2] * 0.125f, o[qg][d][3] * 0.125f};
-      VecIO<bf16_t, 4>::store(dst + d * 16, v);
-    }
-  }
 }
 
 
@@ -1603,9 +1408,9 @@ int launch_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* c
                  int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, void* stream) {
   if (!qkv || !ctx || !P || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
-  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)P) & 7)) return PG_ERR_ALIGN;
+  if ((ld_qkv % 8) || (ld_ctx % 4) || (((uintptr_t)qkv) & 15) || (((uintptr_t)ctx) & 7) || (((uintptr_t)P) & 15)) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
-  if (pg_internal_attn_resident && S <= RES_KEYS && !(((uintptr_t)P) & 15)) {
+  if (pg_internal_attn_resident && S <= RES_KEYS) {
     const dim3 grid(((seq_off ? h.ldS : S) + RES_QB - 1) / RES_QB, n * heads);
     hipLaunchKernelGGL(attn_fwd_p_res_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qkv, mask, (bf16_t*)P,
                        (bf16_t*)ctx, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, h.rg);
@@ -1623,15 +1428,9 @@ int launch_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, co
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 8) || (ld_dq % 4)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)ctx) | ((uintptr_t)dctx)) & 15) return PG_ERR_ALIGN;
-  if ((((uintptr_t)P) | ((uintptr_t)dS) | ((uintptr_t)dq)) & 7) return PG_ERR_ALIGN;
+  if (((uintptr_t)dq) & 7) return PG_ERR_ALIGN;
+  if ((((uintptr_t)P) | ((uintptr_t)dS)) & 15) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
-  if (pg_internal_attn_resident && S <= RES_KEYS && !((((uintptr_t)P) | ((uintptr_t)dS)) & 15)) {
-    const dim3 grid(((seq_off ? h.ldS : S) + RES_QB - 1) / RES_QB, n * heads);
-    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<true>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
-                       (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
-                       (long)ld_ctx, (long)ld_dq, h.rg);
-    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
-  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
                      (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
                      (long)ld_ctx, (long)ld_dq, h.rg);

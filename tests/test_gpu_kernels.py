@@ -671,10 +671,20 @@ def test_fused_attention_forward(pg, S):
             assert float(P[:, :, S:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("S", [40, 200, 512])
-def test_fused_attention_training_passes(pg, S):
+@pytest.fixture
+def attention_kernels(pg, request):
+    """pg_tune key 25: 1 = K / V resident in LDS up to 512 keys (what runs by default), 0 = the ring kernels at every length."""
+    pg._lib.lib.pg_tune(25, request.param)
+    yield request.param
+    pg._lib.lib.pg_tune(25, 1)
+
+
+@pytest.mark.parametrize("S,attention_kernels", [(40, 1), (200, 1), (512, 1), (40, 0), (200, 0), (512, 0), (576, 1)],
+                         indirect=["attention_kernels"])
+def test_fused_attention_training_passes(pg, S, attention_kernels):
     """The three kernels that work on the stored probabilities P, against fp64 on the same
-    bf16-rounded operands (P as the forward kernel stored it):
+    bf16-rounded operands (P as the forward kernel stored it), with the forward and the first-order backward
+    in both their forms (K and V resident in LDS / streamed through the two-buffer ring; 576 keys: ring only):
       first-order backward   dS = P (dP - delta), dq = dS K / 8
       tangent pass           dctx = Pdot V + P dV, rho = rowsum(P dS)
       second-order scores    Sbar, Pdot of the softmax double backward (tests/kernel_specs.py)."""

@@ -49,11 +49,21 @@ def test_plan_lengths_and_extents(pg):
     assert plan_lengths([3, 9], 64, floor=[16, 8]) [0] >= 16
 
 
-def test_ragged_attention_kernels_match_per_sequence(pg):
+@pytest.mark.parametrize("resident", [1, 0])
+def test_ragged_attention_kernels_match_per_sequence(pg, resident):
     """bf16 fused kernels: forward (P written), first-order backward, tangent and second-order passes, and the
     key-side products (one or two reduction segments) over a ragged batch against one rectangular launch per
-    sequence.  Also: score-shaped outputs carry zeros from a sequence's end to the next multiple of 64."""
+    sequence.  Also: score-shaped outputs carry zeros from a sequence's end to the next multiple of 64.
+    `resident`: the forward / first-order backward with K and V resident in LDS, or the ring kernels (pg_tune 25)."""
     lib, ops = pg._lib.lib, pg.ops
+    lib.pg_tune(25, resident)
+    try:
+        _ragged_attention_case(pg, lib, ops)
+    finally:
+        lib.pg_tune(25, 1)
+
+
+def _ragged_attention_case(pg, lib, ops):
     heads, S = 2, 200
     H = heads * 64
     lens = [72, 200, 8, 136]
