@@ -272,6 +272,17 @@ int pg_attention_bwd2_ragged(int dtype, const void* qkv, const void* tqkv, const
                              void* Pdot, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads, int64_t ld_qkv,
                              int64_t ld_ctx, void* stream);
 
+/* The whole attention backward from the stored P in two launches.  First dQ as pg_attention_bwd_dq (dS is written
+ * only when dS != NULL: the gradient penalty keeps it, nothing here reads it) together with the row constants
+ * delta = <dO, O> (fp32 workspace of nseq*heads*max_len); then a key-stationary kernel forms dS again from P, dO,
+ * V and delta in registers and accumulates dK = dS^T Q / 8 and dV = P^T dO per 128 keys: P is read twice in all,
+ * where the two key-side GEMMs read P and dS once each after dS was written.  dqkv: [T][ld_dq] with dQ | dK | dV at
+ * column offsets 0 | H | 2H (H = heads*64).  seq_off == NULL: nseq sequences of max_len rows each (a rectangle).
+ * modeling_bert.py:111-136 (eager_attention_forward) is the forward whose backward this is. */
+int pg_attention_bwd(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dqkv,
+                     float* delta, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads, int64_t ld_qkv,
+                     int64_t ld_ctx, int64_t ld_dq, void* stream);
+
 int pg_score_ld(int S);
 int pg_softmax_fwd(int dtype, const float* scores, const float* mask, void* P, int B, int heads, int S, void* stream);
 /* dS = P * (dP - rowsum(dP*P)) */

@@ -132,6 +132,7 @@ SIGNATURES = {
     "pg_stash_bytes_ragged": (i64, [cfgp, i32, i32, i32, i32]),
     "pg_attention_fwd_p_ragged": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp]),
     "pg_attention_bwd_dq_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp]),
+    "pg_attention_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp]),
     "pg_attention_jvp_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp]),
     "pg_attention_bwd2_ragged": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp]),
     "pg_embed_ln2_packed": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]),

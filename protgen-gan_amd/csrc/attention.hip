@@ -595,18 +595,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_kernel(const bf16_t* __rest
 //   dP = dO V^T ; delta_q = <dO_q, O_q> ; dS = P * (dP - delta) ; dQ = dS K / 8
 // in the same query-on-the-lane formulation as the forward (dP^T = V dO^T has the layout of
 // the score tile; dS, rounded to bf16, is the B operand of dQ^T = K^T dS^T as it stands).
-// dS is written out ([B*heads][S][ldS], like P): the second half (dK = dS^T Q / 8,
-// dV = P^T dO) is two 128x64-tile GEMMs over it, and the gradient penalty keeps it.
+// dS is written out ([B*heads][S][ldS], like P) when STORE_DS: the gradient penalty keeps it, and the
+// second half as two GEMMs (dK = dS^T Q / 8, dV = P^T dO) reads it; attn_bwd_dkv_kernel below forms
+// it again from P and the row constants delta ([B*heads][S of the launch], written when asked for).
+template <bool STORE_DS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
                                                               const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
-                                                              bf16_t* __restrict__ dS, bf16_t* __restrict__ dq, int S, int ldS,
-                                                              int heads, long ld_qkv, long ld_ctx, long ld_dq, RaggedArgs rg) {
+                                                              bf16_t* __restrict__ dS, bf16_t* __restrict__ dq,
+                                                              float* __restrict__ delta_out, int S, int ldS, int heads,
+                                                              long ld_qkv, long ld_ctx, long ld_dq, RaggedArgs rg) {
   __shared__ __align__(16) bf16_t smem[4 * TILE];
   const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
   const int bh = lid / gridDim.x, qt = lid % gridDim.x;
   const int b = bh / heads, h = bh % heads;
   const SeqSpan sp = seq_span(rg, b, S);
   if (qt * QB >= sp.store_rows) return;
+  const int delta_stride = S;  // delta stays [B*heads][S of the launch]
   S = sp.len;
   const long row0 = sp.row0;
   const int lane = threadIdx.x & 63;
@@ -641,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
     delta[qg] = acc;
+    if (delta_out && g == 0 && q0 + qg * 16 + r < S) delta_out[(long)bh * delta_stride + q] = acc;
   }
 
   const ResOffsets ro = res_offsets(r, g);
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
           ds[e] = v;
           dp[qg][2 * j + (e >> 2)][e & 3] = v;
         }
-        if (q < sp.store_rows) VecIO<bf16_t, 8>::store(dSz + (long)q * ldS + t * KT + j * 32 + 8 * g, ds);
+        if (STORE_DS && q < sp.store_rows) VecIO<bf16_t, 8>::store(dSz + (long)q * ldS + t * KT + j * 32 + 8 * g, ds);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -966,6 +971,237 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_p_res_kernel(const bf16_t* __
 }
 
 
+__device__ __forceinline__ void read_kmajor_frags(unsigned tile_addr, const unsigned (&koff)[2][2], u32x4 (&f)[4][2]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    f[0][kk] = rd128<0>(tile_addr + koff[0][kk]);
+    f[1][kk] = rd128<0>(tile_addr + koff[1][kk]);
+    f[2][kk] = rd128<4096>(tile_addr + koff[0][kk]);
+    f[3][kk] = rd128<4096>(tile_addr + koff[1][kk]);
+  }
+}
+
+// Second half of the attention backward, key-stationary, from the stored P:
+//   dV = P^T dO ;  dK = dS^T Q / 8  with  dS = P * (dO V^T - delta)  formed again in registers
+// so P is read once and dS neither read nor (for this half) written.  One workgroup = 4 waves = 128 keys of one
+// (sequence, head), a wave owns 32 of them (two 16-key groups) and keeps their dK^T and dV^T in 64 accumulator
+// registers while the workgroup walks the queries in 64-row tiles: P [64][128 keys], Q [64][64], dO [64][64] and
+// the 64 delta arrive by LDS-DMA into a two-buffer ring.
+// Products are issued key-on-the-lane: dP[q][k] = dO_q . V_k with dO rows as the A operand (row m of block qb is
+// query 32 (qb >> 1) + 8 (m >> 2) + 4 (qb & 1) + (m & 3), the order of res_offsets) and the wave's V rows, read once,
+// as the B operand; a lane (k = lane & 15, g = lane >> 4) then holds, in blocks 2j and 2j + 1, the queries
+// 32 j + 8 g .. + 7 of its key, which is the B operand of a 32-deep step of dV^T += dO^T P and dK^T += Q^T dS
+// as it stands.  P reaches that layout through transposing LDS reads; -delta is the initial accumulator of dP.
+constexpr int DKV_KB = 128;                        // keys per workgroup
+constexpr int DKV_STAGE = 2 * TILE + 64 * DKV_KB + 128;  // bf16 elements: dO | Q | P | delta (64 floats)
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ P,
+                                                               const bf16_t* __restrict__ dctx, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dkv, int S, int ldS, int heads, long ld_qkv,
+                                                               long ld_ctx, long ld_dq, RaggedArgs rg) {
+  __shared__ __align__(16) bf16_t smem[2 * DKV_STAGE];
+  const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int bh = lid / gridDim.x, kb = lid % gridDim.x;
+  const int b = bh / heads, h = bh % heads;
+  const SeqSpan sp = seq_span(rg, b, S);
+  if (kb * DKV_KB >= sp.len) return;
+  const float* drow = delta + (long)bh * S;  // delta stays [B*heads][S of the launch]
+  S = sp.len;
+  const long row0 = sp.row0;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int H = heads * 64;
+  const bf16_t* Q = qkv + row0 * ld_qkv + h * 64;
+  const bf16_t* V = Q + 2 * H;
+  const bf16_t* dO = dctx + row0 * ld_ctx + h * 64;
+  const bf16_t* Pz = P + (long)bh * sp.slot_rows * ldS + kb * DKV_KB;
+  const int nq = (S + 63) / 64;
+  const int chunk_max = (ldS - kb * DKV_KB) / 8 - 1;  // last 16-byte chunk of a P row that belongs to it
+
+  // this wave's pieces of a stage: 4 of P (4 rows x 256 B each), 2 of dO and 2 of Q (8 rows x 128 B each); wave 0: delta
+  auto stage = [&](int t, bf16_t* buf) {
+    const int q0 = t * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wid * 4 + j;
+      int row = q0 + 4 * i + (lane >> 4);
+      row = row < sp.store_rows ? row : sp.store_rows - 1;
+      const int rl = (4 * i + (lane >> 4));
+      int c = (lane & 15) ^ (2 * ((rl & 3) + 4 * ((rl >> 3) & 1)));
+      c = c < chunk_max ? c : chunk_max;
+      __builtin_amdgcn_global_load_lds(Pz + (long)row * ldS + c * 8, buf + 2 * TILE + i * 512, 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wid * 2 + j;
+      int row = q0 + 8 * i + (lane >> 3);
+      row = row < S ? row : S - 1;
+      const int c = (lane & 7) ^ (lane >> 3);
+      __builtin_amdgcn_global_load_lds(dO + (long)row * ld_ctx + c * 8, buf + i * 512, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(Q + (long)row * ld_qkv + c * 8, buf + TILE + i * 512, 16, 0, 0);
+    }
+    if (wid == 0) {
+      int row = q0 + lane;
+      row = row < S ? row : S - 1;
+      __builtin_amdgcn_global_load_lds(drow + row, buf + 2 * TILE + 64 * DKV_KB, 4, 0, 0);
+    }
+  };
+
+  // V rows of this wave's keys (B operand of dP): lane holds V[k][32 kk + 8 g .. + 8]
+  bf16x8_t vfr[2][2];
+  int key[2];
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    key[kg] = kb * DKV_KB + wid * 32 + kg * 16 + r;
+    const int kc = key[kg] < S ? key[kg] : S - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 v = *reinterpret_cast<const uint4*>(V + (long)kc * ld_qkv + kk * 32 + 8 * g);
+      vfr[kg][kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const ResOffsets ro = res_offsets(r, g);
+  unsigned poff[2][2];  // transposing read of P: rows 8 g + 4 hi + (0..3) (+ 32 j), the wave's 16-key group kg
+  {
+    const int qq = r >> 2, pp = r & 3;
+    const int sw = 2 * (qq + 4 * (g & 1));
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        const int row = 8 * g + 4 * hi + qq;
+        const int c = 2 * (wid * 2 + kg) + (pp >> 1);
+        poff[kg][hi] = (unsigned)(row * 256 + ((c ^ sw) << 4) + 8 * (pp & 1));
+      }
+  }
+  const unsigned smem_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
+
+  f32x4 oV[2][4], oK[2][4];
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      oV[kg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      oK[kg][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  stage(0, smem);
+  __syncthreads();
+  for (int t = 0; t < nq; ++t) {
+    if (t + 1 < nq) stage(t + 1, smem + ((t + 1) & 1) * DKV_STAGE);
+    const unsigned da = smem_addr + (t & 1) * DKV_STAGE * 2;  // dO tile
+    const unsigned qa = da + 2 * TILE;                         // Q tile
+    const unsigned pa = qa + 2 * TILE;                         // P tile
+    const unsigned la = pa + 64 * DKV_KB * 2;                  // delta
+    // ---- dP - delta for both key groups
+    f32x4 dp[2][4];
+    {
+      u32x4 af[4][2];
+      read_kmajor_frags(da, ro.koff, af);
+      u32x4 dl[4];
+      dl[0] = rd128<0>(la + 32 * g);
+      dl[1] = rd128<16>(la + 32 * g);
+      dl[2] = rd128<128>(la + 32 * g);
+      dl[3] = rd128<144>(la + 32 * g);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+          f32x4 a = (f32x4){-__uint_as_float(dl[qb][0]), -__uint_as_float(dl[qb][1]), -__uint_as_float(dl[qb][2]),
+                            -__uint_as_float(dl[qb][3])};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[qb][0]), vfr[kg][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[qb][1]), vfr[kg][1], a, 0, 0, 0);
+          dp[kg][qb] = a;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P (raw bits: B operand of dV^T) and dS = P (dP - delta) (B operand of dK^T)
+    bf16x8_t pf[2][2], sf[2][2];
+    {
+      u32x2 pr[2][2][2];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+          pr[kg][0][hi] = rdtr<0>(pa + poff[kg][hi]);
+          pr[kg][1][hi] = rdtr<8192>(pa + poff[kg][hi]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const bool ragged_end = (t == nq - 1) && (S & 63);  // rows past the sequence inside the last tile: P counts as 0
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned pw[4] = {pr[kg][j][0][0], pr[kg][j][0][1], pr[kg][j][1][0], pr[kg][j][1][1]};
+          if (ragged_end) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int q = t * 64 + 32 * j + 8 * g + e;
+              if (q >= S) pw[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+            }
+          }
+          bf16x8_t s8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pe = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+            s8[e] = (__bf16)(pe * dp[kg][2 * j + (e >> 2)][e & 3]);
+          }
+          sf[kg][j] = s8;
+          pf[kg][j] = __builtin_bit_cast(bf16x8_t, ((u32x4){pw[0], pw[1], pw[2], pw[3]}));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const unsigned ta = which ? qa : da;
+      u32x2 lo[2][4], hi[2][4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        lo[0][d] = rdtr<0>(ta + ro.voff[0][d]);
+        hi[0][d] = rdtr<0>(ta + ro.voff[1][d]);
+        lo[1][d] = rdtr<4096>(ta + ro.voff[0][d]);
+        hi[1][d] = rdtr<4096>(ta + ro.voff[1][d]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const u32x4 av = (u32x4){lo[j][d][0], lo[j][d][1], hi[j][d][0], hi[j][d][1]};
+          const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, av);
+#pragma unroll
+          for (int kg = 0; kg < 2; ++kg) {
+            if (which) oK[kg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, sf[kg][j], oK[kg][d], 0, 0, 0);
+            else oV[kg][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, pf[kg][j], oV[kg][d], 0, 0, 0);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // ---- store: lane holds dK[k][h*64 + 16d + 4g .. +4] and the same of dV
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    if (key[kg] >= S) continue;
+    bf16_t* dst = dkv + (row0 + key[kg]) * ld_dq + H + h * 64 + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float kv[4] = {oK[kg][d][0] * 0.125f, oK[kg][d][1] * 0.125f, oK[kg][d][2] * 0.125f, oK[kg][d][3] * 0.125f};
+      float vv[4] = {oV[kg][d][0], oV[kg][d][1], oV[kg][d][2], oV[kg][d][3]};
+      VecIO<bf16_t, 4>::store(dst + d * 16, kv);
+      VecIO<bf16_t, 4>::store(dst + H + d * 16, vv);
+    }
+  }
+}
+
 // ---- gradient-penalty passes over the stored probabilities ---------------------------------
 // Both kernels below keep the query-on-the-lane formulation: a score-shaped product X^T = T R^T
 // takes its A operand from a 64-key LDS tile T (K, dK, V or dV rows, k-major in the head
@@ -997,16 +1233,6 @@ __device__ __forceinline__ void row_dots(const bf16x8_t (&a)[2][2], const bf16x8
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
     out[qg] = acc;
-  }
-}
-
-__device__ __forceinline__ void read_kmajor_frags(unsigned tile_addr, const unsigned (&koff)[2][2], u32x4 (&f)[4][2]) {
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    f[0][kk] = rd128<0>(tile_addr + koff[0][kk]);
-    f[1][kk] = rd128<0>(tile_addr + koff[1][kk]);
-    f[2][kk] = rd128<4096>(tile_addr + koff[0][kk]);
-    f[3][kk] = rd128<4096>(tile_addr + koff[1][kk]);
   }
 }
 
@@ -1421,19 +1647,40 @@ int launch_fwd_p(int dtype, const void* qkv, const float* mask, void* P, void* c
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
-int launch_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dq,
+// dS == NULL: not written (then delta != NULL: a caller without dS has the key side formed from P and delta).
+int launch_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS, void* dq, float* delta,
                   const int32_t* seq_off, int n, int S, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
                   void* stream) {
-  if (!qkv || !P || !ctx || !dctx || !dS || !dq || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
+  if (!qkv || !P || !ctx || !dctx || (!dS && !delta) || !dq || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
   if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
   if ((ld_qkv % 8) || (ld_ctx % 8) || (ld_dq % 4)) return PG_ERR_ALIGN;
   if ((((uintptr_t)qkv) | ((uintptr_t)ctx) | ((uintptr_t)dctx)) & 15) return PG_ERR_ALIGN;
   if (((uintptr_t)dq) & 7) return PG_ERR_ALIGN;
   if ((((uintptr_t)P) | ((uintptr_t)dS)) & 15) return PG_ERR_ALIGN;
   const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
-                     (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, S, h.ldS, heads, (long)ld_qkv,
-                     (long)ld_ctx, (long)ld_dq, h.rg);
+  if (dS)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)dS, (bf16_t*)dq, delta, S, h.ldS, heads, (long)ld_qkv,
+                       (long)ld_ctx, (long)ld_dq, h.rg);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, h.grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, (bf16_t*)nullptr, (bf16_t*)dq, delta, S, h.ldS, heads,
+                       (long)ld_qkv, (long)ld_ctx, (long)ld_dq, h.rg);
+  return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
+}
+
+int launch_bwd_dkv(int dtype, const void* qkv, const void* P, const void* dctx, const float* delta, void* dkv,
+                   const int32_t* seq_off, int n, int S, int tok0, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
+                   void* stream) {
+  if (!qkv || !P || !dctx || !delta || !dkv || n <= 0 || S <= 0 || heads <= 0 || tok0 < 0) return PG_ERR_ARG;
+  if (dtype != PG_BF16 || S > MAX_S) return PG_ERR_UNSUPPORTED;
+  if ((ld_qkv % 8) || (ld_ctx % 8) || (ld_dq % 4)) return PG_ERR_ALIGN;
+  if ((((uintptr_t)qkv) | ((uintptr_t)dctx) | ((uintptr_t)P)) & 15) return PG_ERR_ALIGN;
+  if ((((uintptr_t)dkv) & 7) || (((uintptr_t)delta) & 3)) return PG_ERR_ALIGN;
+  const RaggedHost h = ragged_host(seq_off, n, S, tok0, heads);
+  const dim3 grid(((seq_off ? h.ldS : S) + DKV_KB - 1) / DKV_KB, n * heads);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (const bf16_t*)P,
+                     (const bf16_t*)dctx, delta, (bf16_t*)dkv, S, h.ldS, heads, (long)ld_qkv, (long)ld_ctx, (long)ld_dq, h.rg);
   return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_LAUNCH;
 }
 
@@ -1485,13 +1732,25 @@ extern "C" int pg_attention_fwd_p_ragged(int dtype, const void* qkv, const float
 extern "C" int pg_attention_bwd_dq(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
                                    void* dq, int B, int S, int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq,
                                    void* stream) {
-  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, nullptr, B, S, 0, heads, ld_qkv, ld_ctx, ld_dq, stream);
+  if (!dS) return PG_ERR_ARG;
+  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, nullptr, nullptr, B, S, 0, heads, ld_qkv, ld_ctx, ld_dq, stream);
 }
 extern "C" int pg_attention_bwd_dq_ragged(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx,
                                           void* dS, void* dq, const int32_t* seq_off, int nseq, int max_len, int tok0,
                                           int heads, int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream) {
   if (!seq_off) return PG_ERR_ARG;
-  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, ld_dq, stream);
+  if (!dS) return PG_ERR_ARG;
+  return launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dq, nullptr, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, ld_dq, stream);
+}
+
+extern "C" int pg_attention_bwd(int dtype, const void* qkv, const void* P, const void* ctx, const void* dctx, void* dS,
+                                void* dqkv, float* delta, const int32_t* seq_off, int nseq, int max_len, int tok0, int heads,
+                                int64_t ld_qkv, int64_t ld_ctx, int64_t ld_dq, void* stream) {
+  if (!delta) return PG_ERR_ARG;
+  const int rc = launch_bwd_dq(dtype, qkv, P, ctx, dctx, dS, dqkv, delta, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx,
+                               ld_dq, stream);
+  if (rc != PG_OK) return rc;
+  return launch_bwd_dkv(dtype, qkv, P, dctx, delta, dqkv, seq_off, nseq, max_len, tok0, heads, ld_qkv, ld_ctx, ld_dq, stream);
 }
 
 extern "C" int pg_attention_jvp(int dtype, const void* qkv, const void* tqkv, const void* P, const void* ctx, void* ctxdot,

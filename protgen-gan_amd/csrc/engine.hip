@@ -259,6 +259,7 @@ int pg_internal_fused_dgelu_save = 1;  // pg_tune key 15: GELU backward in the G
 int pg_internal_dw_depth = 0;  // 0 = choose by tile count; 1..4 = force (pg_tune key 13)
 int pg_internal_round_mask = 0;  // pg_tune key 18
 int pg_internal_visible_keys = 1;  // pg_tune key 20: inference attention over the visible keys only
+int pg_internal_attn_key_stationary = 1;  // pg_tune key 26: 0 = dk, dv of the first-order backward as two GEMMs over dS and P
 namespace {
 // Layers per grouped launch: the count in 1..4 whose tiles fill whole rounds of the 256 CUs best.
 inline int dw_depth(const Dims& d, int dtype) {
@@ -712,7 +713,11 @@ extern "C" int pg_encoder_backward(const pg_model_cfg* cfg, const pg_params* p, 
     // dctx = da Wo   (dWo = da^T ctx waits for dWqkv below: 64 + 192 tiles fill the chip together)
     CK(g.run(a.a, true, H, pv.w(pv.lo(l, PG_L_WO)), false, H, a.ctx, dtype, H, T, H, H, 1.f, 0.f));
     // attention: dP = dctx V^T ; dS = softmax_bwd ; dq = dS K/8 ; dk = dS^T Q/8 ; dv = P^T dctx
-    if (fused) {
+    if (fused && pg_internal_attn_key_stationary) {
+      // dq, then dk and dv from P alone: dS is written only where the second-order pass will read it (kept adjoints)
+      CK(pg_attention_bwd(dtype, s.qkv, s.ss, s.ctx, a.ctx, save ? a.ss : nullptr, a.qkv, w.sc0, rag.on() ? rag.off : nullptr, B,
+                          S, rag.on() ? rag.tok0 : 0, d.nh, 3 * H, H, 3 * H, st));
+    } else if (fused) {
       if (rag.on())
         CK(pg_attention_bwd_dq_ragged(dtype, s.qkv, s.ss, s.ctx, a.ctx, a.ss, a.qkv, rag.off, B, S, rag.tok0, d.nh, 3 * H, H,
                                       3 * H, st));

@@ -802,6 +802,7 @@ extern int pg_internal_round_mask;
 extern int pg_internal_visible_keys;
 extern int pg_internal_fused_dgelu_save;
 extern int pg_internal_attn_resident;
+extern int pg_internal_attn_key_stationary;
 extern "C" int pg_tune(int key, int value) {
   if (key == 0) { g_gemm_path = value; return PG_OK; }
   if (key == 1) { g_gemm_narrow = value; return PG_OK; }
@@ -824,6 +825,7 @@ extern "C" int pg_tune(int key, int value) {
   if (key == 8) { if (value < 1) return PG_ERR_ARG; g_gemm_group_m = value; return PG_OK; }
   if (key == 23) { g_gemm_epi_prefetch = value ? 1 : 0; return PG_OK; }
   if (key == 25) { pg_internal_attn_resident = value ? 1 : 0; return PG_OK; }
+  if (key == 26) { pg_internal_attn_key_stationary = value ? 1 : 0; return PG_OK; }
   return PG_ERR_ARG;
 }
 

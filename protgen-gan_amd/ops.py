@@ -288,6 +288,21 @@ def attention_bwd_dq(qkv, P, ctx, dctx, B, S, heads):
     return dS, dq
 
 
+def attention_bwd(qkv, P, ctx, dctx, heads, B=None, S=None, seq_off=None, max_len=None, keep_dS=True):
+    """The whole attention backward over stored P (pg_attention_bwd: dq with the row constants, then the key-stationary
+    dk / dv kernel).  Rectangle: pass B, S; ragged rows: pass seq_off, max_len.  Returns (dqkv [T, 3H], dS or None)."""
+    n, width = (B, S) if seq_off is None else (seq_off.numel() - 1, max_len)
+    ld = score_ld(width)
+    rows = width if seq_off is None else ld
+    dS = torch.zeros(n * heads, rows, ld, dtype=qkv.dtype, device=qkv.device) if keep_dS else None
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(n * heads, width, dtype=torch.float32, device=qkv.device)
+    check(lib.pg_attention_bwd(dt_code(qkv.dtype), qkv.data_ptr(), P.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), ptr(dS),
+                               dqkv.data_ptr(), delta.data_ptr(), ptr(seq_off), n, width, 0, heads, qkv.stride(0),
+                               ctx.stride(0), dqkv.stride(0), stream()), "pg_attention_bwd")
+    return dqkv, dS
+
+
 def attention_jvp(qkv, tqkv, P, ctx, B, S, heads):
     """Tangent pass over stored P: returns (dctx [B*S,H], rho [B*heads,S] fp32)."""
     H = heads * 64

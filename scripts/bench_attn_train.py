@@ -78,11 +78,16 @@ for name, d in (("3B = 24 sequences", full), ("B = 8 sequences", part)):
                                                         p(d["gctx"]), p(d["ctxbar"]), p(d["rho"]), p(d["Sbar"][i]), p(d["Pdot"][i]),
                                                         so, B, S, 0, heads, 3 * H, H, st), 3, 5),
     }
+    delta = torch.empty(B * heads, S, device=DEV)
+    kern["bwd, dS kept"] = (lambda i: lib.pg_attention_bwd(1, p(d["qkv"]), p(d["P"][i]), p(d["ctx"]), p(d["dctx"]), p(d["dS"][i]),
+                                                           p(d["dq"]), p(delta), so, B, S, 0, heads, 3 * H, H, 3 * H, st), 3, 5)
+    kern["bwd, no dS"] = (lambda i: lib.pg_attention_bwd(1, p(d["qkv"]), p(d["P"][i]), p(d["ctx"]), p(d["dctx"]), None,
+                                                         p(d["dq"]), p(delta), so, B, S, 0, heads, 3 * H, H, 3 * H, st), 2, 5)
     print(f"{name}: {T} token rows, score-shaped buffer {score_bytes / 1e6:.0f} MB per slot")
     for k, (fn, nbuf, nprod) in kern.items():
         assert fn(0) == 0
         us = timeit(fn, NSETS)
-        print(f"  {k:7s} {us:7.1f} us   score-shaped traffic {nbuf * score_bytes / us / 1e6:5.2f} TB/s   "
+        print(f"  {k:12s} {us:7.1f} us   score-shaped traffic {nbuf * score_bytes / us / 1e6:5.2f} TB/s   "
               f"{nprod * fl_unit / us / 1e6:5.0f} TFLOP/s ({nprod} products)", flush=True)
 
 # the inference forward of the fill loop: 68 sequences, all keys visible / half of them (walk over the visible-key list)

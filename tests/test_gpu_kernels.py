@@ -712,6 +712,15 @@ def test_fused_attention_training_passes(pg, S, attention_kernels):
     dS, dq = pg.ops.attention_bwd_dq(d(qkv), P_d, ctx_d, d(gctx), B, S, nh)
     close(dS[:, :, :S], dS_ref.reshape(Z, S, S), bf)
     close(dq, flat(dS_ref @ k) * 0.125, bf)
+    # the whole backward in two launches: dq as above, dk / dv by the key-stationary kernel (dS formed again from P)
+    for keep in (True, False):
+        dqkv, dS2 = pg.ops.attention_bwd(d(qkv), P_d, ctx_d, d(gctx), nh, B=B, S=S, keep_dS=keep)
+        assert (dS2 is None) == (not keep)
+        if keep:
+            assert torch.equal(dS2, dS)
+        assert torch.equal(dqkv[:, :H], dq)
+        close(dqkv[:, H:2 * H], flat(dS_ref.transpose(2, 3) @ q) * 0.125, bf)
+        close(dqkv[:, 2 * H:], flat(P.transpose(2, 3) @ heads(gctx)), bf)
     # tangent pass
     Sd = (qd @ k.transpose(2, 3) + q @ kd.transpose(2, 3)) * 0.125
     rho_ref = (P * Sd).sum(-1, keepdim=True)

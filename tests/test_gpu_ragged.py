@@ -49,8 +49,8 @@ def test_plan_lengths_and_extents(pg):
     assert plan_lengths([3, 9], 64, floor=[16, 8]) [0] >= 16
 
 
-@pytest.mark.parametrize("resident", [1, 0])
-def test_ragged_attention_kernels_match_per_sequence(pg, resident):
+@pytest.mark.parametrize("resident,S,lens", [(1, 200, [72, 200, 8, 136]), (0, 200, [72, 200, 8, 136]), (1, 1024, [600, 1024, 72, 520])])
+def test_ragged_attention_kernels_match_per_sequence(pg, resident, S, lens):
     """bf16 fused kernels: forward (P written), first-order backward, tangent and second-order passes, and the
     key-side products (one or two reduction segments) over a ragged batch against one rectangular launch per
     sequence.  Also: score-shaped outputs carry zeros from a sequence's end to the next multiple of 64.
@@ -58,15 +58,14 @@ def test_ragged_attention_kernels_match_per_sequence(pg, resident):
     lib, ops = pg._lib.lib, pg.ops
     lib.pg_tune(25, resident)
     try:
-        _ragged_attention_case(pg, lib, ops)
+        _ragged_attention_case(pg, lib, ops, S, lens)
     finally:
         lib.pg_tune(25, 1)
 
 
-def _ragged_attention_case(pg, lib, ops):
-    heads, S = 2, 200
+def _ragged_attention_case(pg, lib, ops, S, lens):
+    heads = 2
     H = heads * 64
-    lens = [72, 200, 8, 136]
     rg = _ragged(pg, lens, S)
     T, B, ld = rg.T, len(lens), ops.score_ld(S)
     g = torch.Generator().manual_seed(5)
@@ -74,7 +73,7 @@ def _ragged_attention_case(pg, lib, ops):
     qkv, tqkv = rnd(T, 3 * H), rnd(T, 3 * H, sc=0.5)
     dctx, gctx, ctxbar = rnd(T, H), rnd(T, H), rnd(T, H)
     mask = torch.ones(T, device=DEV)
-    mask[rg.off[1] + 150:rg.off[1] + 160] = 0   # holes inside a sequence
+    mask[rg.off[1] + lens[1] - 50:rg.off[1] + lens[1] - 40] = 0   # holes inside a sequence
     mask[rg.off[3] + 3] = 0
     st = ops.stream()
     dt = 1
@@ -117,6 +116,9 @@ def _ragged_attention_case(pg, lib, ops):
         assert lib.pg_gemm(C.byref(d), st) == 0
         return out[:, H:H + heads * 64]
     dK = kside(dS, qkv)
+    # the whole first-order backward in two launches (dq, then the key-stationary dk / dv kernel), with and without dS kept
+    dqkv_a, dS_a = ops.attention_bwd(qkv, P, ctx, dctx, heads, seq_off=rg.seq_off, max_len=S, keep_dS=True)
+    dqkv_b, _ = ops.attention_bwd(qkv, P, ctx, dctx, heads, seq_off=rg.seq_off, max_len=S, keep_dS=False)
     kbar = kside(Sbar, qkv, dS, tqkv)
     qbar = kside(Sbar, qkv, dS, tqkv, a_kmajor=True, col=H)  # (Sbar K + dS Kdot) / 8
     torch.cuda.synchronize()
@@ -136,6 +138,14 @@ def _ragged_attention_case(pg, lib, ops):
         dS1, dq1 = ops.attention_bwd_dq(q1, P1, c1, dctx[sl].contiguous(), 1, L, heads)
         assert torch.equal(dS[b * heads:(b + 1) * heads][:, :L, :ld1], dS1), b
         assert torch.equal(dq[sl, :H], dq1), b
+        dqkv1, _ = ops.attention_bwd(q1, P1, c1, dctx[sl].contiguous(), heads, B=1, S=L)
+        assert torch.equal(dS_a[b * heads:(b + 1) * heads][:, :L, :ld1], dS1), b
+        assert torch.equal(dqkv_a[sl], dqkv1) and torch.equal(dqkv_b[sl], dqkv1), b
+        for h in range(heads):  # dk = dS^T Q / 8 and dv = P^T dO against fp32 matmuls over the very bf16 operands
+            Q1, dO1 = q1[:, h * 64:(h + 1) * 64].float(), dctx[sl][:, h * 64:(h + 1) * 64].float()
+            for col, ref in ((H, dS1[h, :, :L].float().T @ Q1 / 8), (2 * H, P1[h, :, :L].float().T @ dO1)):
+                gh = dqkv1[:, col + h * 64:col + (h + 1) * 64].float()
+                assert float((gh - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-6, (b, h, col)
         cd1, rho1 = ops.attention_jvp(q1, t1, P1, c1, 1, L, heads)
         assert torch.equal(ctxdot[sl], cd1), b
         assert torch.equal(rho[b * heads:(b + 1) * heads, :L], rho1), b
