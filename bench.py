@@ -177,7 +177,8 @@ def main():
 
     # the next iteration's fakes are filled on a side stream beside this iteration's updates (every timed step still
     # runs one whole fill and one whole set of updates; what step i consumes was filled during step i - 1)
-    ahead = pgt.FillAhead(dev) if (not soft and not args.no_fill_ahead) else None
+    # (at the device's lowest stream priority when no gradient reduction runs beside it: train.FILL_STREAM_LOW_PRIORITY)
+    ahead = pgt.FillAhead(dev, low_priority=not use_sync) if (not soft and not args.no_fill_ahead) else None
 
     def one_step(i, ahead=ahead):
         if seeds is not None:
@@ -365,7 +366,9 @@ def main():
                     "max": round(max(step_ms), 2), "each": [round(v, 1) for v in step_ms],
                     "fill_token_rows_each": fill_rows},
         "c_loss": c_loss, "g_loss": g_loss,
-        "schedule": (("next iteration's fill beside this iteration's updates (train.FillAhead)" if ahead is not None
+        "schedule": (("next iteration's fill beside this iteration's updates (train.FillAhead"
+                      + (", on a stream of the lowest priority)" if not use_sync and pgt.FILL_STREAM_LOW_PRIORITY else ")")
+                      if ahead is not None
                       else "fill, then updates")
                      + ("; critic updates in two lanes" if pgt.TWO_STREAM_BACKWARD_DEFAULT and args.regime == "unfrozen" else "")),
         "one_after_the_other": serial,

@@ -731,6 +731,40 @@ def generator_update_soft(generator: Generator, critic: Critic, gen_optimizer, m
     return g_loss.detach()
 
 
+# FillAhead(low_priority=True): the fill's stream is created at the lowest priority the device offers, so that its
+# workgroups take the CUs the updates leave idle instead of competing with them launch by launch (one GPU, same box:
+# 704.3 -> 691.0 ms per GAN step).  Only without a gradient reduction beside it: with the layer-wise all-reduce on its
+# own stream the low-priority fill was starved until the updates had finished (947 against 721 ms per step in a one-rank
+# RCCL rehearsal), so the data-parallel callers leave it off.  The updates stay on the caller's stream either way: giving
+# THEM a high-priority stream instead hung a blocking host-to-device copy of the main thread about once in four runs of
+# the trainer tests; this form ran those tests 20 times over.  PG_FILL_LOW_PRIORITY=0 turns it off everywhere.
+FILL_STREAM_LOW_PRIORITY = os.environ.get("PG_FILL_LOW_PRIORITY", "1") == "1"
+
+
+def _low_priority_stream(device) -> "torch.cuda.Stream":
+    """A stream of the device's least priority (torch.cuda.Stream offers normal and high only): created through the HIP
+    runtime torch itself uses, wrapped as an external stream, never destroyed (it lives as long as the process)."""
+    import ctypes as C
+    torch.cuda.init()
+    path = None
+    with open("/proc/self/maps") as maps:  # the copy of the HIP runtime torch loaded (torch ships its own), not another one
+        for line in maps:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    if path is None:
+        raise RuntimeError("no HIP runtime is loaded in this process")
+    hip = C.CDLL(path)
+    least, greatest = C.c_int(0), C.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0:
+        raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        if hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), least) != 0:  # 1 = hipStreamNonBlocking
+            raise RuntimeError("hipStreamCreateWithPriority failed")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 class FillAhead:
     """The NEXT iteration's fake batches, filled while THIS iteration's updates run.
 
@@ -745,11 +779,18 @@ class FillAhead:
     device generator in fill order.  So the fake batches, the alphas and with them every loss are the ones the
     one-iteration-at-a-time schedule produces.  Not for the soft generator update (it changes the generator)."""
 
-    def __init__(self, device):
+    def __init__(self, device, low_priority: bool = False):
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = None
+        if low_priority and FILL_STREAM_LOW_PRIORITY:
+            try:
+                self.stream = _low_priority_stream(self.device)
+            except (RuntimeError, OSError, AttributeError):  # (a scheduling hint only: any stream serves)
+                self.stream = None
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(self.device)
         self._thread: Optional[threading.Thread] = None
         self._out = None
         self._err: Optional[BaseException] = None

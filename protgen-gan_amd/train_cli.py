@@ -162,7 +162,7 @@ class EngineSteps(Steps):
         self.ahead = None
         if (args.mode == "blind" and self.stacked and not bool(getattr(args, "soft_generator_update", False))
                 and not bool(getattr(args, "no_fill_ahead", False))):
-            self.ahead = T.FillAhead(device)
+            self.ahead = T.FillAhead(device, low_priority=world <= 1)  # (see train.FILL_STREAM_LOW_PRIORITY)
         if self.soft and not self.stacked:
             raise ValueError("--soft_generator_update needs the stacked fill: drop --reference_draw_order")
         self.n_critic = args.n_critic
