@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256) void key_compact_kernel(const float* __restric
   if (threadIdx.x == 0) cnt[b] = (bad || running == 0) ? -1 : running;
 }
 
+// 2^x as the one hardware instruction (v_exp_f32; arguments here are <= 0, results below 2^-126 may flush to zero, which
+// is what a probability that small rounds to in bf16 anyway)
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;
+
 template <int IMM>
 __device__ __forceinline__ int rd32(unsigned addr) {
   int v;
@@ -302,20 +307,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = s[qg][blk][e] * 0.125f + madd[blk][e];
+          const float v = s[qg][blk][e] * kScaleLog2e + madd[blk][e];  // (base-2 exponent: exp(x / 8) = 2^(x log2(e) / 8))
           s[qg][blk][e] = v;
           mx = fmaxf(mx, v);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[qg], mx);
-      const float alpha = __expf(m_run[qg] - m_new);
+      const float alpha = exp2_fast(m_run[qg] - m_new);
       float sum = 0.f;
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __expf(s[qg][blk][e] - m_new);
+          const float p = exp2_fast(s[qg][blk][e] - m_new);
           s[qg][blk][e] = p;
           sum += p;
         }
