@@ -144,7 +144,8 @@ int pg_gemm_group(const pg_gemm_desc* d, int n, void* stream);
  * operand several row blocks at a time (0/1, default 1); key 25: the forward that writes P keeps K / V of sequences of at
  * most 512 keys resident in LDS and makes one pass (0 = two sweeps over the K / V ring at every length; default 1);
  * key 26: dk, dv of the first-order attention backward from the key-stationary kernel of pg_attention_bwd (0 = two
- * GEMMs over dS and P; default 1).  Other keys: PG_ERR_ARG. */
+ * GEMMs over dS and P; default 1).  Other keys: PG_ERR_ARG.
+ * PG_TUNE="key=value,..." in the environment applies the same settings once, when the library is loaded. */
 int pg_tune(int key, int value);
 /* Measurement aid (no reference counterpart): time every `sample_every`-th pg_gemm launch
  * with HIP events on its own stream.  pg_profile_end synchronises those events, stops the

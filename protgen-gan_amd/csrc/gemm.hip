@@ -16,6 +16,9 @@
 // ds_read_b128; m-major bf16 fragments with the transposing ds_read_b64_tr_b16.
 // The MFMA is issued with the operands swapped (D = Bt * At) so that a lane owns four
 // consecutive n of one output row, which makes every epilogue access an 8/16-byte vector.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 #include <deque>
 #include <mutex>
@@ -830,6 +833,29 @@ extern "C" int pg_tune(int key, int value) {
 }
 
 namespace {
+// PG_TUNE="key=value,key=value" in the environment is applied once, when the library is loaded (the same keys as pg_tune):
+// a deployment that wants a switch off sets it there and never calls pg_tune; an entry that does not parse or that
+// pg_tune refuses is reported on stderr and skipped.
+struct TuneFromEnv {
+  TuneFromEnv() {
+    const char* e = getenv("PG_TUNE");
+    if (!e) return;
+    std::string s(e);
+    size_t pos = 0;
+    while (pos < s.size()) {
+      size_t end = s.find(',', pos);
+      if (end == std::string::npos) end = s.size();
+      const std::string item = s.substr(pos, end - pos);
+      pos = end + 1;
+      if (item.empty()) continue;
+      int k = 0, v = 0;
+      if (sscanf(item.c_str(), "%d=%d", &k, &v) != 2 || pg_tune(k, v) != PG_OK)
+        fprintf(stderr, "libprotgen_hip: PG_TUNE entry '%s' ignored\n", item.c_str());
+    }
+  }
+};
+TuneFromEnv g_tune_from_env;
+
 int gemm_prepare(const pg_gemm_desc* d, GemmArgs& a);
 ProfEntry* prof_begin(int variant, double flops, hipStream_t st);
 }  // namespace

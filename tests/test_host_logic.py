@@ -140,3 +140,20 @@ def test_hf_written_checkpoint_fixture_has_every_parameter(pg, golden_dir):
             assert n in sd and tuple(sd[n].shape) == tuple(B._shape_of(cfg, n)), n
     assert "cls.predictions.decoder.weight" in binf and "cls.predictions.decoder.weight" not in st
     assert torch.equal(binf["cls.predictions.decoder.weight"], binf["bert.embeddings.word_embeddings.weight"])
+
+
+def test_pg_tune_from_the_environment_at_load():
+    """PG_TUNE="key=value,..." is applied when the library is loaded (no compute call, no GPU): a valid entry is taken
+    silently, an unknown key or a malformed entry is named on stderr and skipped."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "protgen-gan_amd", "libprotgen_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libprotgen_hip.so not built")
+    code = "import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); print(l.pg_tune(25, 1))"
+    env = dict(os.environ, PG_TUNE="25=0,999=1,nonsense,26=1")
+    r = subprocess.run([sys.executable, "-c", code, lib], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "0"
+    assert "'999=1' ignored" in r.stderr and "'nonsense' ignored" in r.stderr
+    assert "'25=0'" not in r.stderr and "'26=1'" not in r.stderr
