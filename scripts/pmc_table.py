@@ -9,7 +9,8 @@ names = []
 for r in csv.DictReader(open(f)):
     if (sys.argv[2] if len(sys.argv) > 2 else "gemm") not in r["Kernel_Name"]:
         continue
-    d = rows.setdefault(int(r["Dispatch_Id"]), {"k": r["Kernel_Name"].split("<")[0].split("(")[0].split("::")[-1],
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    d = rows.setdefault(int(r["Dispatch_Id"]), {"k": name.split("(")[0].split("::")[-1][:28],
                                                 "wgs": int(r["Grid_Size"]) // int(r["Workgroup_Size"])})
     c = r["Counter_Name"]
     if c not in names:
@@ -18,3 +19,17 @@ for r in csv.DictReader(open(f)):
 print("dispatch kernel wgs " + " ".join(names))
 for i, d in rows.items():
     print(f"{i:4d} {d['k']:28s} {d['wgs']:6d} " + " ".join(f"{d.get(c, 0):.4g}" for c in names))
+
+# per kernel (median dispatch): shares of wave lifetime, and the matrix pipes' share of the launch
+if "SQ_WAVE_CYCLES" in names and "GRBM_GUI_ACTIVE" in names:
+    by = collections.OrderedDict()
+    for d in rows.values():
+        by.setdefault((d["k"], d["wgs"]), []).append(d)
+    print()
+    print("kernel, workgroups: us at 2.1 GHz | instructions issued / VALU / waiting, as shares of wave lifetime | matrix pipes busy, share of the launch (1024 SIMDs)")
+    for (k, w), ds in by.items():
+        d = sorted(ds, key=lambda x: x["GRBM_GUI_ACTIVE"])[len(ds) // 2]
+        cyc = d["GRBM_GUI_ACTIVE"] / 8
+        wc = d["SQ_WAVE_CYCLES"]
+        print(f"{k:28s} {w:6d}: {cyc / 2100:7.1f} us | {d.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.2f} {d.get('SQ_ACTIVE_INST_VALU', 0) / wc:5.2f} "
+              f"{d.get('SQ_WAIT_ANY', 0) / wc:5.2f} | {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (cyc * 1024):5.2f}")
